@@ -1,0 +1,197 @@
+/* Plain-C restatement of PVNet's RANSAC voting path -- TEST INFRASTRUCTURE (oracle), NOT PRODUCT CODE.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load the library built from this
+ * file (oracle/Makefile -> oracle/_build/libpvnet_vote_ref.so).  The product never links or calls it.
+ *
+ * Follows, line by line in float32 with ONE rounding per operation (build with -ffp-contract=off):
+ *   lib/ransac_voting_gpu_layer/src/ransac_voting_kernel.cu:11-49    generate_hypothesis_kernel
+ *   lib/ransac_voting_gpu_layer/src/ransac_voting_kernel.cu:88-126   voting_for_hypothesis_kernel
+ *   lib/ransac_voting_gpu_layer/ransac_voting_gpu.py:514-598         ransac_voting_layer_v3 (one round; the
+ *        reference's later rounds re-use the same idxs (:547 vs :552) and cannot change the result)
+ *   lib/ransac_voting_gpu_layer/ransac_voting_gpu.py:503-512         b_inv (2x2)
+ * The reference itself cannot be compiled here (CUDA kernels, removed ATen APIs): parity is unpinned by the
+ * reference; this file is cross-checked bit-for-bit against the independent numpy float32 restatement in
+ * oracle/ransac_voting_oracle.py and both against the demo-fixture known answer (tests/test_oracle.py).
+ *
+ * It doubles as the CPU baseline ("port") that bench.py times on the host cores (OpenMP over hypotheses).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define TAG_HYP 0x48595031u
+#define TAG_SUB 0x53554231u
+
+static inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x21F0AAADu; x ^= x >> 15; x *= 0x735A2D97u; x ^= x >> 15; return x;
+}
+/* restatement of pvnet_amd/csrc/pvnet_rng.h */
+uint32_t ref_rng_u32(uint64_t seed, uint32_t tag, uint32_t stream, uint32_t counter) {
+    uint32_t x = mix32((uint32_t)seed ^ tag);
+    x = mix32((x ^ (stream * 0x9E3779B1u)) + (uint32_t)(seed >> 32));
+    x = mix32(x ^ (counter * 0x85EBCA77u));
+    return x;
+}
+
+int ref_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void ref_set_num_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* ransac_voting_kernel.cu:22-48 for one (hi,vi) */
+static inline void hyp_one(const float* direct, const float* coords, int vn, int vi, int t0, int t1,
+                           float* ox, float* oy) {
+    float nx0 = direct[t0 * vn * 2 + vi * 2 + 1];
+    float ny0 = -direct[t0 * vn * 2 + vi * 2];
+    float cx0 = coords[t0 * 2], cy0 = coords[t0 * 2 + 1];
+    float nx1 = direct[t1 * vn * 2 + vi * 2 + 1];
+    float ny1 = -direct[t1 * vn * 2 + vi * 2];
+    float cx1 = coords[t1 * 2], cy1 = coords[t1 * 2 + 1];
+    float dety = nx1 * ny0 - nx0 * ny1;
+    float detx = ny1 * nx0 - ny0 * nx1;
+    *ox = 0.f; *oy = 0.f;                                   /* at::zeros, :75 */
+    if ((double)fabsf(dety) < 1e-6) return;                 /* :42 */
+    if ((double)fabsf(detx) < 1e-6) return;                 /* :43 */
+    float b0 = nx0 * cx0 + ny0 * cy0;
+    float b1 = nx1 * cx1 + ny1 * cy1;
+    *oy = (nx1 * b0 - nx0 * b1) / dety;                     /* :44 */
+    *ox = (ny1 * b0 - ny0 * b1) / detx;                     /* :45 */
+}
+
+/* direct [tn,vn,2], coords [tn,2], idxs [hn,vn,2] -> hyp [hn,vn,2] */
+void ref_generate_hypothesis(const float* direct, const float* coords, const int32_t* idxs, float* hyp,
+                             int tn, int vn, int hn) {
+    (void)tn;
+    for (int hvi = 0; hvi < hn * vn; ++hvi) {
+        int hi = hvi / vn, vi = hvi - hi * vn;
+        hyp_one(direct, coords, vn, vi, idxs[hvi * 2], idxs[hvi * 2 + 1], &hyp[hvi * 2], &hyp[hvi * 2 + 1]);
+    }
+}
+
+/* ransac_voting_kernel.cu:107-125 for one (hypothesis, pixel) pair */
+static inline int inlier_one(float cx, float cy, float nx, float ny, float hx, float hy, float thresh) {
+    float dx = hx - cx, dy = hy - cy;
+    float norm1 = sqrtf(nx * nx + ny * ny);
+    float norm2 = sqrtf(dx * dx + dy * dy);
+    if ((double)norm1 < 1e-6 || (double)norm2 < 1e-6) return 0;
+    float ang = (dx * nx + dy * ny) / (norm1 * norm2);
+    return ang > thresh;
+}
+
+/* the op as the reference exposes it: sets 1s in inliers [hn,vn,tn], never clears */
+void ref_voting_for_hypothesis(const float* direct, const float* coords, const float* hyp, uint8_t* inliers,
+                               int tn, int vn, int hn, float thresh) {
+#pragma omp parallel for schedule(static)
+    for (int hv = 0; hv < hn * vn; ++hv) {
+        int vi = hv % vn;
+        float hx = hyp[hv * 2], hy = hyp[hv * 2 + 1];
+        uint8_t* row = inliers + (size_t)hv * tn;
+        for (int ti = 0; ti < tn; ++ti)
+            if (inlier_one(coords[ti * 2], coords[ti * 2 + 1], direct[ti * vn * 2 + vi * 2],
+                           direct[ti * vn * 2 + vi * 2 + 1], hx, hy, thresh))
+                row[ti] = 1;
+    }
+}
+
+/* torch.sum(cur_inlier, 2) without the tensor (ransac_voting_gpu.py:557-561): counts [hn,vn] int32 */
+void ref_voting_counts(const float* direct, const float* coords, const float* hyp, int32_t* counts,
+                       int tn, int vn, int hn, float thresh) {
+#pragma omp parallel for schedule(static)
+    for (int hv = 0; hv < hn * vn; ++hv) {
+        int vi = hv % vn;
+        float hx = hyp[hv * 2], hy = hyp[hv * 2 + 1];
+        int c = 0;
+        for (int ti = 0; ti < tn; ++ti)
+            c += inlier_one(coords[ti * 2], coords[ti * 2 + 1], direct[ti * vn * 2 + vi * 2],
+                            direct[ti * vn * 2 + vi * 2 + 1], hx, hy, thresh);
+        counts[hv] = c;
+    }
+}
+
+/* Whole layer for a batch.  fg: [b,h,w] uint8 foreground flags (caller applies mask.byte()!=0);
+ * vertex element (bi,y,x,k,c) at vertex[bi*vs[0]+y*vs[1]+x*vs[2]+k*vs[3]+c*vs[4]] (strides in elements);
+ * idxs: NULL (counter RNG) or [b,hn,vn,2]; out [b,vn,2]; win_idx/win_cnt [b,vn] optional.
+ * Refinement accumulates in float64 (the "oracle32 + f64 LSQ" flavour of the numpy oracle). Returns 0. */
+int ref_vote_v3(const uint8_t* fg, const float* vertex, const int64_t* vs, int b, int h, int w, int vn, int hn,
+                float thresh, int min_num, int max_num, uint64_t seed, const int32_t* idxs, float* out,
+                int32_t* win_idx_out, int32_t* win_cnt_out) {
+    for (int bi = 0; bi < b; ++bi) {
+        const uint8_t* m = fg + (size_t)bi * h * w;
+        float* o = out + (size_t)bi * vn * 2;
+        for (int i = 0; i < vn * 2; ++i) o[i] = 0.f;
+        int tn0 = 0;
+        for (int p = 0; p < h * w; ++p) tn0 += m[p] != 0;                          /* :527-528 */
+        if (tn0 < min_num) continue;                                                /* :531-534 */
+        uint64_t thr = 1ull << 32;
+        if (tn0 > max_num) {                                                        /* :537-540 */
+            float p = (float)max_num / (float)tn0;
+            double t = ceil((double)p * 4294967296.0);
+            thr = t >= 4294967296.0 ? (1ull << 32) : (uint64_t)t;
+        }
+        float* coords = (float*)malloc(sizeof(float) * 2 * (size_t)tn0);
+        float* direct = (float*)malloc(sizeof(float) * 2 * (size_t)vn * tn0);
+        int tn = 0;
+        for (int y = 0; y < h; ++y)                                                 /* :542-546, raster order */
+            for (int x = 0; x < w; ++x) {
+                int p = y * w + x;
+                if (!m[p]) continue;
+                if (thr < (1ull << 32) && (uint64_t)ref_rng_u32(seed, TAG_SUB, (uint32_t)bi, (uint32_t)p) >= thr)
+                    continue;
+                coords[tn * 2] = (float)x; coords[tn * 2 + 1] = (float)y;
+                const float* v = vertex + bi * vs[0] + y * vs[1] + x * vs[2];
+                for (int k = 0; k < vn; ++k) {
+                    direct[(tn * vn + k) * 2] = v[k * vs[3]];
+                    direct[(tn * vn + k) * 2 + 1] = v[k * vs[3] + vs[4]];
+                }
+                ++tn;
+            }
+        if (tn == 0) { free(coords); free(direct); continue; }
+        int32_t* ix = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)hn * vn);      /* :547 */
+        for (int i = 0; i < hn * vn * 2; ++i)
+            ix[i] = idxs ? idxs[(size_t)bi * hn * vn * 2 + i]
+                         : (int32_t)(((uint64_t)ref_rng_u32(seed, TAG_HYP, (uint32_t)bi, (uint32_t)i) * (uint64_t)tn) >> 32);
+        float* hyp = (float*)malloc(sizeof(float) * 2 * (size_t)hn * vn);
+        int32_t* counts = (int32_t*)malloc(sizeof(int32_t) * (size_t)hn * vn);
+        ref_generate_hypothesis(direct, coords, ix, hyp, tn, vn, hn);               /* :554 */
+        ref_voting_counts(direct, coords, hyp, counts, tn, vn, hn, thresh);         /* :557-561 */
+        for (int k = 0; k < vn; ++k) {
+            int best = 0, bc = counts[k];                                           /* :562 (first max) */
+            for (int hi = 1; hi < hn; ++hi)
+                if (counts[hi * vn + k] > bc) { bc = counts[hi * vn + k]; best = hi; }
+            float wx = 0.f, wy = 0.f;                                               /* :548-549,567-569: a zero */
+            if (bc > 0) { wx = hyp[(best * vn + k) * 2]; wy = hyp[(best * vn + k) * 2 + 1]; } /* ratio never wins */
+            if (win_idx_out) win_idx_out[bi * vn + k] = best;
+            if (win_cnt_out) win_cnt_out[bi * vn + k] = bc;
+            double a = 0, bb = 0, d = 0, r0 = 0, r1 = 0;                            /* :579-594 */
+            int cnt = 0;
+            for (int ti = 0; ti < tn; ++ti) {
+                float ux = direct[(ti * vn + k) * 2], uy = direct[(ti * vn + k) * 2 + 1];
+                if (!inlier_one(coords[ti * 2], coords[ti * 2 + 1], ux, uy, wx, wy, thresh)) continue;
+                double nx = uy, ny = -(double)ux;
+                double bv = nx * coords[ti * 2] + ny * coords[ti * 2 + 1];
+                a += nx * nx; bb += nx * ny; d += ny * ny; r0 += nx * bv; r1 += ny * bv;
+                ++cnt;
+            }
+            double det = a * d - bb * bb;
+            if (cnt == 0 || det == 0 || !isfinite(det)) { o[k * 2] = wx; o[k * 2 + 1] = wy; continue; }
+            o[k * 2] = (float)((d * r0 - bb * r1) / det);
+            o[k * 2 + 1] = (float)((-bb * r0 + a * r1) / det);
+        }
+        free(coords); free(direct); free(ix); free(hyp); free(counts);
+    }
+    return 0;
+}
