@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""bench.py -- RANSAC votings/s of the HIP voting layer on synthetic 480x640 fields (BASELINE.json config 3).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the whole voting path (mask + 9-key-point vector field -> 9 key-points) over one
+batch of 32 synthetic images per GPU, inputs resident in HBM.  With N > 1 every rank votes its own 32 images
+(weak scaling, no data-path collective) and the step ends with the path's one real exchange: an RCCL
+all-gather of the [32, 9, 2] key-points.  Rank 0 prints ONE JSON line.
+
+Besides the contract's fields the line carries
+  roofline      the dominant kernel (inlier scoring).  It is fp32-VALU bound, not HBM bound, so
+                `achieved` is algorithmic TFLOP/s (12 flop x hn*vn*tn pair tests) against the
+                157.3 TFLOP/s fp32 vector peak (= the dense f32 MFMA rate on gfx950); duration measured live
+                with hipEvents on the op's stream (pvnet_vote_v3_profiled).
+  roofline_hbm  the whole path against the HBM roofline: algorithmic bytes (24 576 072 B per voting with the
+                int64 mask) x votings / time of all seven launches, peak 8 TB/s.
+  cpu_baseline  the plain-C restatement (oracle, OpenMP over all host cores) timed on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from pvnet_amd import synth, voting  # noqa: E402
+
+H, W, VN, HN = 480, 640, 9, 1024
+BATCH = 32
+THRESH = 0.99
+BYTES_PER_VOTING = H * W * 8 + H * W * VN * 2 * 4 + VN * 2 * 4  # 24 576 072 (SURVEY.md 8d, int64 mask)
+FLOP_PER_PAIR = 12
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = f32 MFMA dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--radius", type=int, default=40, help="disk radius of the synthetic object mask (tn ~ pi r^2)")
+    ap.add_argument("--buffers", type=int, default=2, help="distinct input sets cycled (2 x 786 MB > 256 MiB L3)")
+    ap.add_argument("--clean", action="store_true", help="noise-free field (default: noisy, net-like background)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def make_inputs(rank, nbuf, radius, noisy, dev):
+    sets = []
+    for s in range(nbuf):
+        mask, planar, _ = synth.make_batch(BATCH, first_index=(rank * nbuf + s) * BATCH, h=H, w=W, vn=VN,
+                                           radius=radius, noise=noisy, background="normal" if noisy else "zeros")
+        m = torch.from_numpy(mask).to(dev)  # int64, as torch.argmax delivers it (tools/demo.py:52)
+        p = torch.from_numpy(planar).to(dev)  # [b, 2vn, h, w] planar, as the backbone emits it
+        sets.append((m, synth.planar_to_vertex_view(p), mask, planar))
+    return sets
+
+
+def cpu_baseline(sets, seconds):
+    """the oracle (plain-C port, OpenMP) on a bounded sample of the same workload -- reported, never the target"""
+    from oracle import cref
+    from oracle import ransac_voting_oracle as O
+    cref.build()
+    _, _, mask, planar = sets[0]
+    vnp = synth.planar_to_vertex_view(planar)
+    fg = O.foreground(mask)
+    cref.vote_v3(fg[:1], vnp[:1], HN, THRESH, seed=1)  # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        cref.vote_v3(fg[n % BATCH:n % BATCH + 1], vnp[n % BATCH:n % BATCH + 1], HN, THRESH, seed=1)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds or n >= 4 * BATCH:
+            break
+    return {"value": n / el, "unit": "votings/s", "cores": cref.num_threads(), "kind": "port",
+            "sample": f"{n} images of the bench workload (480x640, 9 kpts, 1024 hyp), {el:.1f} s, "
+                      f"oracle/oracle_c/pvnet_vote_ref.c with OpenMP on {cref.num_threads()} threads "
+                      f"(host has {os.cpu_count()} logical cpus)"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    voting.load_library()
+
+    sets = make_inputs(rank, a.buffers, a.radius, not a.clean, dev)
+    gathered = torch.empty((world * BATCH, VN, 2), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step(i, **kw):
+        m, v, _, _ = sets[i % len(sets)]
+        out = voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=1234 + i, **kw)
+        if world > 1 and not kw:
+            dist.all_gather_into_tensor(gathered, out)  # the single RCCL gather of 2-D key-points over xGMI
+        return out
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel: live hipEvent stage timing over the same K steps ------------------
+    stage_sum = {}
+    tn_sum = 0
+    for i in range(a.steps):
+        _, dbg, times = step(i, return_debug=True, stage_times=True)
+        if i < len(sets):
+            tn_sum += int(dbg["tn"].sum().item())
+        for k, v in times.items():
+            stage_sum[k] = stage_sum.get(k, 0.0) + v
+    stage_ms = {k: v / a.steps for k, v in stage_sum.items()}
+    tn_per_batch = tn_sum / min(a.steps, len(sets))
+    pairs = HN * VN * tn_per_batch  # pair tests per launch of the scoring kernel
+    score_s = stage_ms["score"] * 1e-3
+    path_s = sum(stage_ms.values()) * 1e-3
+
+    if rank == 0:
+        votings_per_s = world * BATCH * a.steps / dt
+        res = {
+            "metric": "RANSAC votings/s (480x640, 9 kpts, batch 32) + HBM GB/s vs roofline",
+            "value": votings_per_s, "unit": "votings/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: batch=32 synthetic 480x640 fields per GPU, 9 keypoints, "
+                                   "1024 hypotheses, inlier_thresh 0.99, int64 mask, planar strided field",
+                       "batch_per_gpu": BATCH, "global_batch": world * BATCH, "h": H, "w": W, "vn": VN, "hn": HN,
+                       "mask_radius": a.radius, "mean_foreground_px": tn_per_batch / BATCH,
+                       "field": "clean" if a.clean else "noisy (0.05 rad + 10% outliers), N(0,1) background",
+                       "input_sets_cycled": len(sets), "parallelism": f"images sharded over {world} GPU(s)"},
+            "roofline": {"kernel": "score_kernel", "bound": "valu", "achieved": FLOP_PER_PAIR * pairs / score_s / 1e12,
+                         "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": FLOP_PER_PAIR * pairs / score_s / 1e12 / PEAK_F32_TFLOPS, "traffic": None,
+                         "avg_launch_ms": stage_ms["score"], "pair_tests_per_launch": pairs,
+                         "note": "fp32 vector peak = dense f32 MFMA rate on gfx950; no MFMA used (irregular "
+                                 "gather/reduce); 12 flop per pair test as SURVEY.md 8d counts them"},
+            "roofline_hbm": {"bound": "hbm", "achieved": BYTES_PER_VOTING * BATCH / path_s / 1e9,
+                             "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": BYTES_PER_VOTING * BATCH / path_s / 1e9 / PEAK_HBM_GBS,
+                             "bytes_per_voting": BYTES_PER_VOTING, "path_ms": path_s * 1e3,
+                             "end_to_end_frac": BYTES_PER_VOTING * votings_per_s / world / 1e9 / PEAK_HBM_GBS},
+            "stage_ms": stage_ms,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sets, a.cpu_seconds)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

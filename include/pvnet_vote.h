@@ -1,0 +1,138 @@
+/* pvnet_vote.h -- C ABI of the MI355X-native RANSAC voting layer (libpvnet_vote.so).
+ *
+ * Drop-in boundary for the reference's `lib/ransac_voting_gpu_layer`:
+ *   - pvnet_vote_v3()                 replaces the whole of ransac_voting_layer_v3
+ *                                     (lib/ransac_voting_gpu_layer/ransac_voting_gpu.py:514-598), i.e. the Python
+ *                                     loop plus the ~40 torch launches and the two extension ops per image;
+ *   - pvnet_generate_hypothesis()     replaces the pybind op `generate_hypothesis`
+ *                                     (src/ransac_voting.cpp:20-31 -> src/ransac_voting_kernel.cu:51-86);
+ *   - pvnet_voting_for_hypothesis()   replaces the pybind op `voting_for_hypothesis`
+ *                                     (src/ransac_voting.cpp:41-55 -> src/ransac_voting_kernel.cu:129-167).
+ * Plain pointers and sizes only (no torch types).  All pointers are DEVICE pointers unless marked host.
+ * Every entry point only enqueues work on `stream` (a hipStream_t passed as void*): no allocation, no
+ * host synchronisation, no global state -- re-entrant and hipGraph-capturable.  (pvnet_vote_v3_profiled is the
+ * one exception: it records events and synchronises, and exists for bench.py / profiling only.)
+ *
+ * Return value: 0 on success, a positive hipError_t from the runtime, or a negative PVNET_E_* code.
+ * Unlike the reference (src/cuda_common.h:19-26 prints and exit()s) nothing here ever terminates the process.
+ */
+#ifndef PVNET_VOTE_H_
+#define PVNET_VOTE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PVNET_VOTE_ABI_VERSION 1
+
+/* negative library error codes */
+#define PVNET_E_BADARG      (-1)   /* null pointer / non-positive size / unsupported dtype or stride */
+#define PVNET_E_WORKSPACE   (-2)   /* workspace_bytes smaller than pvnet_vote_workspace_bytes() */
+#define PVNET_E_UNSUPPORTED (-3)   /* e.g. vn or hn beyond the compiled limits */
+
+/* mask element types (foreground <=> (uint8)value != 0, i.e. torch's `.byte()` of ransac_voting_gpu.py:527) */
+#define PVNET_MASK_U8   0          /* uint8 / int8 / bool */
+#define PVNET_MASK_I16  1
+#define PVNET_MASK_I32  2
+#define PVNET_MASK_I64  3          /* what torch.argmax delivers (tools/demo.py:52) */
+#define PVNET_MASK_F32  4
+
+/* flags */
+#define PVNET_F_LITERAL   1u       /* score with the reference's float32 operation order (sqrt + divide, one
+                                      rounding per op): bit-exact with oracle32.  Default: sqrt-free form. */
+#define PVNET_F_NO_REFINE 2u       /* skip ransac_voting_gpu.py:579-595, return the winning hypotheses */
+
+/* per-(image,key-point) status bits written to out_status */
+#define PVNET_S_SKIPPED   1        /* fewer than min_num foreground pixels (or none kept): zeros returned */
+#define PVNET_S_SINGULAR  2        /* normal matrix singular: winning hypothesis returned (reference raises) */
+#define PVNET_S_NO_INLIER 4        /* best hypothesis had zero inliers: (0,0) carried into refinement */
+#define PVNET_S_OVERFLOW  8        /* kept pixels exceeded the workspace capacity and were truncated */
+
+/* Layout of the caller-owned workspace (byte offsets).  Exposed so tests and tools can read the
+ * intermediate products (compacted pixels, hypotheses, inlier counts) without extra copies. */
+typedef struct PvnetVoteLayout {
+    int32_t b, h, w, vn, hn;
+    int32_t cap;            /* per-image capacity of the compacted pixel list (multiple of 8, incl. pad)   */
+    int32_t words;          /* 64-pixel words per image in the foreground bit mask                          */
+    int32_t chunk;          /* pixels per scoring work item                                                 */
+    int32_t max_chunks;     /* ceil(cap / chunk)                                                            */
+    int32_t hpl;            /* hypotheses per lane in the scoring kernel                                    */
+    int32_t hgroups;        /* hypothesis groups per key-point = ceil(hn / (64*hpl))                        */
+    int32_t hn_pad;         /* hgroups * 64 * hpl                                                           */
+    size_t off_ctrl;        /* int32 [b][8]: tn0, tn, status, item_base, nchunks, -, -, -  ; then [8] global */
+    size_t off_bits;        /* uint64 [b][words]           foreground (after subsampling) bit mask          */
+    size_t off_pix;         /* int32  [b][cap]             linear pixel index y*w+x of compacted pixel t    */
+    size_t off_rec;         /* float4 [b][vn][cap]         scoring record (x, y, mx, my)                    */
+    size_t off_dir;         /* float2 [b][vn][cap]         raw direction (ux, uy)                           */
+    size_t off_hyp;         /* float2 [b][vn][hn_pad]      hypotheses                                       */
+    size_t off_partial;     /* uint16 [b][vn][max_chunks][hn_pad]  per-chunk inlier counts                  */
+    size_t off_counts;      /* int32  [b][vn][hn_pad]      inlier count of every hypothesis                 */
+    size_t off_win;         /* int32  [b][vn][2]           (winner index, winner count)                     */
+    size_t total_bytes;
+} PvnetVoteLayout;
+
+/* Host-only: fills *out for a problem size.  max_num as passed to pvnet_vote_v3. */
+int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVoteLayout* out);
+
+/* Host-only: bytes of workspace pvnet_vote_v3 needs (0 on invalid arguments). 256-byte aligned base required. */
+size_t pvnet_vote_workspace_bytes(int b, int h, int w, int vn, int hn, int max_num);
+
+/* The whole layer.  Replaces ransac_voting_layer_v3 (ransac_voting_gpu.py:514-598).
+ *   mask            [b,h,w] of mask_dtype, element strides mask_strides[3]
+ *   vertex          [b,h,w,vn,2] float32, element strides vertex_strides[5] (any; planar in practice)
+ *   hn              round_hyp_num
+ *   inlier_thresh, min_num, max_num   as the reference's keyword arguments
+ *   seed            counter-RNG seed (pixel pairs when idxs == NULL; Bernoulli subsample when tn0 > max_num)
+ *   idxs            NULL, or int32 [b,hn,vn,2] pixel-pair indices into each image's compacted list
+ *   out_kpts        [b,vn,2] float32
+ *   out_status      NULL or int32 [b,vn] PVNET_S_* bits
+ * The reference's `confidence` / `max_iter` do not exist here: its loop re-uses one idxs draw (:547 vs :552) so
+ * rounds after the first can never change the result (SURVEY.md finding 3). */
+int pvnet_vote_v3(const void* mask, int mask_dtype, const int64_t mask_strides[3],
+                  const float* vertex, const int64_t vertex_strides[5],
+                  int b, int h, int w, int vn, int hn,
+                  float inlier_thresh, int min_num, int max_num,
+                  uint64_t seed, const int32_t* idxs, uint32_t flags,
+                  float* out_kpts, int32_t* out_status,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* Same call, timed stage by stage with hipEvents on `stream`; synchronises the stream before returning.
+ * stage_ms (host, PVNET_NUM_STAGES floats) receives the GPU time of each stage of this call. bench/profiling only. */
+#define PVNET_STAGE_MASK      0   /* mask -> bit mask + foreground count          (HBM read of the mask)     */
+#define PVNET_STAGE_SUBSAMPLE 1   /* Bernoulli subsample when tn0 > max_num                                  */
+#define PVNET_STAGE_COMPACT   2   /* order-preserving compaction + vector gather  (HBM read of fg vectors)   */
+#define PVNET_STAGE_PLAN      3   /* work-item prefix                                                        */
+#define PVNET_STAGE_HYP       4   /* hypothesis generation                                                   */
+#define PVNET_STAGE_SCORE     5   /* inlier scoring (dominant, fp32 VALU)                                    */
+#define PVNET_STAGE_REFINE    6   /* arg-max + least-squares refinement                                      */
+#define PVNET_NUM_STAGES      7
+int pvnet_vote_v3_profiled(const void* mask, int mask_dtype, const int64_t mask_strides[3],
+                           const float* vertex, const int64_t vertex_strides[5],
+                           int b, int h, int w, int vn, int hn,
+                           float inlier_thresh, int min_num, int max_num,
+                           uint64_t seed, const int32_t* idxs, uint32_t flags,
+                           float* out_kpts, int32_t* out_status,
+                           void* workspace, size_t workspace_bytes, void* stream, float* stage_ms);
+
+/* Op-level entry points with the reference extension's tensor layouts.
+ * direct [tn,vn,2] f32, coords [tn,2] f32, idxs [hn,vn,2] i32 -> hypo_pts [hn,vn,2] f32 (fully written; degenerate
+ * pairs give (0,0) as the reference's at::zeros + early return do, ransac_voting_kernel.cu:42-43,75). */
+int pvnet_generate_hypothesis(const float* direct, const float* coords, const int32_t* idxs, float* hypo_pts,
+                              int tn, int vn, int hn, void* stream);
+
+/* inliers [hn,vn,tn] uint8, in/out: a 1 is stored where the pixel votes for the hypothesis, other bytes are left
+ * untouched (ransac_voting_kernel.cu:124-125).  Float32 operation order of the reference (literal mode). */
+int pvnet_voting_for_hypothesis(const float* direct, const float* coords, const float* hypo_pts, uint8_t* inliers,
+                                int tn, int vn, int hn, float inlier_thresh, void* stream);
+
+/* ABI / build identification (host-only) */
+int pvnet_vote_abi_version(void);
+const char* pvnet_vote_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVNET_VOTE_H_ */

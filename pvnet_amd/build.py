@@ -1,0 +1,49 @@
+"""Builds libpvnet_vote.so (the C-ABI HIP library) in-tree for gfx950 with hipcc.
+
+    python -m pvnet_amd.build            # build if sources are newer than the library
+    python -m pvnet_amd.build --force
+
+hipcc cross-compiles without a GPU.  The library lands next to this file so that it travels with the tree."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = [os.path.join(HERE, "csrc", "pvnet_vote.hip")]
+DEPS = SRC + [os.path.join(HERE, "csrc", "pvnet_rng.h"), os.path.join(ROOT, "include", "pvnet_vote.h")]
+LIB = os.path.join(HERE, "libpvnet_vote.so")
+ARCH = "gfx950"
+
+
+def hipcc_path() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
+
+
+def flags():
+    return ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared", "-fno-fast-math",
+            "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-Wall", "-Wno-unused-function"]
+
+
+def up_to_date() -> bool:
+    return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and up_to_date():
+        return LIB
+    cmd = [hipcc_path()] + flags() + SRC + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,887 @@
+// pvnet_vote.hip -- hand-written gfx950 (MI355X / CDNA4) implementation of PVNet's RANSAC voting layer.
+//
+// Path replaced (reference tree): lib/ransac_voting_gpu_layer/ransac_voting_gpu.py:514-598
+// (ransac_voting_layer_v3) together with the two CUDA kernels it drives,
+// src/ransac_voting_kernel.cu:11-49 (generate_hypothesis) and :88-126 (voting_for_hypothesis).
+// Not a translation: the reference runs a Python loop per image with ~40 torch launches, materialises an
+// [hn,vn,tn] uint8 inlier tensor and syncs with the host 6-8 times per image.  Here a whole batch is seven
+// launches on the caller's stream, nothing of size hn*tn ever touches HBM, and there is no host sync.
+//
+// Stages (one launch each, all images of the batch at once):
+//   K1 mask_bits      mask (any int dtype / f32, any strides) -> 1 bit per pixel + foreground count   [HBM read]
+//   K1b subsample     Bernoulli(max_num/tn0) thinning of the bit mask when tn0 > max_num (device decision)
+//   K2 compact        order-preserving (raster) compaction: wave ballot/popcount prefix; gathers the vn
+//                     direction vectors of each foreground pixel straight from the strided field (planar in
+//                     practice -> consecutive lanes read consecutive addresses) and writes per-(image,kp)
+//                     scoring records (x, y, mx, my) as float4                                         [HBM read]
+//   K2b plan          per-image chunk counts and the exclusive prefix of scoring work items
+//   K3 hypotheses     one thread per (image, kp, h): two pixel draws (counter RNG or caller idxs), 2x2 solve
+//   K4 score          DOMINANT, fp32 VALU bound.  "Lane owns hypotheses": every lane keeps HPL hypotheses and
+//                     their counters in VGPRs; the pixel records of a chunk are wave-uniform and arrive
+//                     through the scalar cache (s_load_dwordx8/16 -> SGPR operands of the VALU ops), so the
+//                     inner loop is a pure v_sub/v_fma/v_cmp/v_addc stream with no LDS, no cross-lane traffic
+//                     and no barriers.  Work items (image, kp, hypothesis group, pixel chunk) are strided over
+//                     a persistent grid; per-chunk counts go out as uint16.
+//   K5 select+refine  sums the chunk counts, arg-max with first-index tie-break (wave shuffles), recomputes the
+//                     winner's inliers and solves the 2x2 normal equations, accumulated in float64 centred on
+//                     the winner (the reference's un-centred float32 sums are ~2e-3 px noisy).
+//
+// Wave size is 64 everywhere (ballots are 64-bit).  Build: hipcc --offload-arch=gfx950 (see build.py).
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "pvnet_rng.h"
+#include "pvnet_vote.h"
+
+namespace {
+
+// (double)x < 1e-6   <=>   x <= kF1e6   for float x   [float(1e-6) = 0x1.0c6f7ap-20 < 1e-6]
+__device__ constexpr float kF1e6 = 0x1.0c6f7ap-20f;
+
+constexpr int CTRL_STRIDE = 8;
+enum { C_TN0 = 0, C_TN = 1, C_STATUS = 2, C_ITEM_BASE = 3, C_NCHUNKS = 4 };
+
+constexpr int K1_WORDS_PER_WAVE = 8;   // 8 x 64 pixels per wave, 8 independent loads in flight per lane
+constexpr int K2_WORDS_PER_BLOCK = 64; // 4096 pixels per compaction block
+constexpr int PAD = 8;                 // scoring consumes records 8 at a time; tails are padded with sentinels
+
+struct VoteParams {
+    const void* mask;
+    int64_t ms0, ms1, ms2;
+    int mask_dtype, mask_linear;
+    const float* vertex;
+    int64_t vs0, vs1, vs2, vs3, vs4;
+    int b, h, w, vn, hn, npix, words, cap, chunk, max_chunks, hpl, hgroups, hn_pad;
+    float thresh;
+    int min_num, max_num;
+    uint64_t seed;
+    const int32_t* idxs;
+    uint32_t flags;
+    int32_t* ctrl;
+    uint64_t* bits;
+    int32_t* pix;
+    float4* rec;
+    float2* dir;
+    float2* hyp;
+    uint16_t* partial;
+    int32_t* counts;
+    int32_t* win;
+    float* out;
+    int32_t* status;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// arithmetic shared by several kernels
+// ------------------------------------------------------------------------------------------------------------
+
+// ransac_voting_kernel.cu:28-48 in its float32 operation order, one rounding per operation (no FMA contraction)
+__device__ __forceinline__ void hyp_intersect(float ux0, float uy0, float cx0, float cy0, float ux1, float uy1,
+                                              float cx1, float cy1, float& ox, float& oy) {
+#pragma clang fp contract(off)
+    const float nx0 = uy0, ny0 = -ux0, nx1 = uy1, ny1 = -ux1;
+    const float dety = nx1 * ny0 - nx0 * ny1;
+    const float detx = ny1 * nx0 - ny0 * nx1;
+    ox = 0.f;
+    oy = 0.f;
+    if (fabsf(dety) <= kF1e6 || fabsf(detx) <= kF1e6) return;
+    const float b0 = nx0 * cx0 + ny0 * cy0;
+    const float b1 = nx1 * cx1 + ny1 * cy1;
+    oy = (nx1 * b0 - nx0 * b1) / dety;
+    ox = (ny1 * b0 - ny0 * b1) / detx;
+}
+
+// ransac_voting_kernel.cu:107-125, literal float32 order (sqrt and divide correctly rounded)
+__device__ __forceinline__ bool inlier_literal(float cx, float cy, float nx, float ny, float hx, float hy,
+                                               float thresh) {
+#pragma clang fp contract(off)
+    const float dx = hx - cx, dy = hy - cy;
+    const float norm1 = __builtin_sqrtf(nx * nx + ny * ny);
+    const float norm2 = __builtin_sqrtf(dx * dx + dy * dy);
+    if (norm1 <= kF1e6 || norm2 <= kF1e6) return false;
+    const float ang = (dx * nx + dy * ny) / (norm1 * norm2);
+    return ang > thresh;
+}
+
+// sqrt-free form of the same predicate on a pre-scaled record: m = n / (|n| * thresh), thresh > 0
+//   cos > thresh  <=>  d.m > |d|  <=>  (d.m)|d.m| > |d|^2
+__device__ __forceinline__ bool inlier_fast(float cx, float cy, float mx, float my, float hx, float hy) {
+    const float dx = hx - cx, dy = hy - cy;
+    const float dot = fmaf(dy, my, dx * mx);
+    const float l2 = fmaf(dy, dy, dx * dx);
+    return dot * fabsf(dot) > l2;
+}
+
+__device__ __forceinline__ int wave_reduce_add(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_reduce_add(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_reduce_max(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long t = __shfl_down(v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K1: mask -> bit mask + foreground count                     (ransac_voting_gpu.py:527-528)
+// ------------------------------------------------------------------------------------------------------------
+template <int DT>
+__device__ __forceinline__ bool load_fg(const void* m, int64_t off) {
+    if (DT == PVNET_MASK_U8) return reinterpret_cast<const uint8_t*>(m)[off] != 0;
+    if (DT == PVNET_MASK_I16) return (reinterpret_cast<const uint16_t*>(m)[off] & 0xFFu) != 0;
+    if (DT == PVNET_MASK_I32) return (reinterpret_cast<const uint32_t*>(m)[off] & 0xFFu) != 0;
+    if (DT == PVNET_MASK_I64) return (reinterpret_cast<const uint64_t*>(m)[off] & 0xFFull) != 0;
+    const float v = reinterpret_cast<const float*>(m)[off];  // torch .byte() of a float: truncate, wrap
+    return (static_cast<long long>(v) & 0xFF) != 0;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void mask_bits_kernel(VoteParams P) {
+    const int bi = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int word0 = (blockIdx.x * 4 + wave) * K1_WORDS_PER_WAVE;
+    bool f[K1_WORDS_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < K1_WORDS_PER_WAVE; ++i) {
+        const int p = (word0 + i) * 64 + lane;
+        bool v = false;
+        if (p < P.npix) {
+            int64_t off;
+            if (P.mask_linear) {
+                off = (int64_t)bi * P.ms0 + p;
+            } else {
+                const int y = p / P.w, x = p - y * P.w;
+                off = (int64_t)bi * P.ms0 + (int64_t)y * P.ms1 + (int64_t)x * P.ms2;
+            }
+            v = load_fg<DT>(P.mask, off);
+        }
+        f[i] = v;
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < K1_WORDS_PER_WAVE; ++i) {
+        const unsigned long long m = __ballot(f[i]);
+        if (lane == 0 && word0 + i < P.words) P.bits[(size_t)bi * P.words + word0 + i] = m;
+        cnt += __popcll(m);
+    }
+    __shared__ int s_cnt[4];
+    if (lane == 0) s_cnt[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (t) atomicAdd(&P.ctrl[bi * CTRL_STRIDE + C_TN0], t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K1b: Bernoulli subsample when tn0 > max_num                 (ransac_voting_gpu.py:537-540)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void subsample_kernel(VoteParams P) {
+    const int bi = blockIdx.y;
+    const int tn0 = P.ctrl[bi * CTRL_STRIDE + C_TN0];
+    if (tn0 <= P.max_num) return;  // wave-uniform: the common case costs one scalar load
+    const float p = (float)P.max_num / (float)tn0;
+    const double t = ceil((double)p * 4294967296.0);
+    if (t >= 4294967296.0) return;
+    const uint32_t thr = (uint32_t)t;
+    const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_SUB, (uint32_t)bi);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int word0 = (blockIdx.x * 4 + wave) * K1_WORDS_PER_WAVE;
+    for (int i = 0; i < K1_WORDS_PER_WAVE; ++i) {
+        const int j = word0 + i;
+        if (j >= P.words) break;
+        const unsigned long long word = P.bits[(size_t)bi * P.words + j];
+        if (word == 0) continue;
+        const bool keep = ((word >> lane) & 1ull) && pvnet_rng_at(key, (uint32_t)(j * 64 + lane)) < thr;
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) P.bits[(size_t)bi * P.words + j] = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K2: order-preserving compaction + direction gather          (ransac_voting_gpu.py:542-546)
+// ------------------------------------------------------------------------------------------------------------
+template <bool LITERAL>
+__global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
+    const int bi = blockIdx.y;
+    const int w0 = blockIdx.x * K2_WORDS_PER_BLOCK;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t* bw = P.bits + (size_t)bi * P.words;
+
+    __shared__ int s_red[4];
+    __shared__ int s_woff[K2_WORDS_PER_BLOCK];
+    __shared__ uint64_t s_word[K2_WORDS_PER_BLOCK];
+    __shared__ int s_total;
+
+    // pixels kept before this block = popcount of all earlier words (<= 38 KB of L2-resident bit mask)
+    int part = 0;
+    for (int j = threadIdx.x; j < w0; j += 256) part += __popcll(bw[j]);
+    part = wave_reduce_add(part);
+    if (lane == 0) s_red[wave] = part;
+    if (wave == 0) {  // exclusive scan of this block's 64 word popcounts
+        const unsigned long long wd = (w0 + lane < P.words) ? bw[w0 + lane] : 0ull;
+        const int c = __popcll(wd);
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        s_word[lane] = wd;
+        s_woff[lane] = incl - c;
+        if (lane == 63) s_total = incl;
+    }
+    __syncthreads();
+    const int base = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    const int usable = P.cap - PAD;
+    const float inv_t = 1.0f / P.thresh;
+
+    for (int i = 0; i < K2_WORDS_PER_BLOCK / 4; ++i) {
+        const int jj = wave * (K2_WORDS_PER_BLOCK / 4) + i;
+        const unsigned long long word = s_word[jj];
+        if (word == 0) continue;  // wave-uniform: rows without foreground cost nothing
+        const bool bit = (word >> lane) & 1ull;
+        const int pos = base + s_woff[jj] + __popcll(word & ((1ull << lane) - 1ull));
+        if (bit && pos < usable) {
+            const int p = (w0 + jj) * 64 + lane;
+            const int y = p / P.w, x = p - y * P.w;
+            P.pix[(size_t)bi * P.cap + pos] = p;
+            const float* v = P.vertex + (int64_t)bi * P.vs0 + (int64_t)y * P.vs1 + (int64_t)x * P.vs2;
+            for (int k = 0; k < P.vn; ++k) {
+                const float ux = v[(int64_t)k * P.vs3];
+                const float uy = v[(int64_t)k * P.vs3 + P.vs4];
+                const size_t o = ((size_t)bi * P.vn + k) * P.cap + pos;
+                P.dir[o] = make_float2(ux, uy);
+                float mx = ux, my = uy;
+                if (!LITERAL) {
+                    const float n1 = __builtin_sqrtf(fmaf(uy, uy, ux * ux));
+                    const float s = (n1 <= kF1e6) ? 0.f : inv_t / n1;  // zero direction never votes (:121)
+                    mx = ux * s;
+                    my = uy * s;
+                }
+                P.rec[o] = make_float4((float)x, (float)y, mx, my);
+            }
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1) {  // the block that owns the last word knows the total
+        const int total = base + s_total;
+        const int tn = total < usable ? total : usable;
+        if (threadIdx.x == 0) {
+            P.ctrl[bi * CTRL_STRIDE + C_TN] = tn;
+            if (total > usable) P.ctrl[bi * CTRL_STRIDE + C_STATUS] = PVNET_S_OVERFLOW;
+        }
+        const int tpad = (tn + PAD - 1) / PAD * PAD;  // sentinel records: zero direction never votes
+        for (int i = threadIdx.x; i < (tpad - tn) * P.vn; i += 256) {
+            const int k = i / (tpad - tn), t = tn + i - k * (tpad - tn);
+            P.rec[((size_t)bi * P.vn + k) * P.cap + t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K2b: chunk counts + exclusive prefix of scoring work items   (gates of ransac_voting_gpu.py:531-534)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void plan_kernel(VoteParams P) {
+    __shared__ int s_scan[256];
+    __shared__ int s_running;
+    if (threadIdx.x == 0) s_running = 0;
+    __syncthreads();
+    for (int base = 0; base < P.b; base += 256) {
+        const int i = base + threadIdx.x;
+        int n = 0;
+        if (i < P.b) {
+            const int tn0 = P.ctrl[i * CTRL_STRIDE + C_TN0];
+            const int tn = P.ctrl[i * CTRL_STRIDE + C_TN];
+            const bool skip = tn0 < P.min_num || tn <= 0;
+            const int nch = skip ? 0 : (tn + P.chunk - 1) / P.chunk;
+            P.ctrl[i * CTRL_STRIDE + C_NCHUNKS] = nch;
+            if (skip) P.ctrl[i * CTRL_STRIDE + C_STATUS] |= PVNET_S_SKIPPED;
+            n = nch * P.vn * P.hgroups;
+        }
+        s_scan[threadIdx.x] = n;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int t = threadIdx.x >= o ? s_scan[threadIdx.x - o] : 0;
+            __syncthreads();
+            s_scan[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < P.b) P.ctrl[i * CTRL_STRIDE + C_ITEM_BASE] = s_running + s_scan[threadIdx.x] - n;
+        __syncthreads();
+        if (threadIdx.x == 255) s_running += s_scan[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) P.ctrl[P.b * CTRL_STRIDE] = s_running;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K3: hypotheses                                               (ransac_voting_gpu.py:547,554; kernel.cu:11-49)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
+    const int bi = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.hn * P.vn) return;
+    const int h = i / P.vn, k = i - h * P.vn;
+    float hx = 0.f, hy = 0.f;
+    if (P.ctrl[bi * CTRL_STRIDE + C_NCHUNKS] > 0) {
+        const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
+        int t0, t1;
+        if (P.idxs) {
+            t0 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2];
+            t1 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2 + 1];
+            t0 = t0 < 0 ? 0 : (t0 >= tn ? tn - 1 : t0);  // memory safety only; valid idxs are untouched
+            t1 = t1 < 0 ? 0 : (t1 >= tn ? tn - 1 : t1);
+        } else {
+            const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_HYP, (uint32_t)bi);
+            t0 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u), (uint32_t)tn);
+            t1 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u + 1u), (uint32_t)tn);
+        }
+        const int p0 = P.pix[(size_t)bi * P.cap + t0], p1 = P.pix[(size_t)bi * P.cap + t1];
+        const float2 d0 = P.dir[((size_t)bi * P.vn + k) * P.cap + t0];
+        const float2 d1 = P.dir[((size_t)bi * P.vn + k) * P.cap + t1];
+        const int y0 = p0 / P.w, y1 = p1 / P.w;
+        hyp_intersect(d0.x, d0.y, (float)(p0 - y0 * P.w), (float)y0, d1.x, d1.y, (float)(p1 - y1 * P.w), (float)y1,
+                      hx, hy);
+    }
+    P.hyp[((size_t)bi * P.vn + k) * P.hn_pad + h] = make_float2(hx, hy);
+}
+
+typedef __attribute__((address_space(4))) const float CFloat;
+
+constexpr int NB = 4;       // records per scalar-load batch (one s_load_dwordx16)
+constexpr int RB = NB * 4;  // floats per batch
+
+// 4 records = one s_load_dwordx16 into SGPRs (address is wave-uniform, constant address space)
+__device__ __forceinline__ void load_batch(const CFloat* r, int p, float (&q)[RB]) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) q[i] = r[p * 4 + i];
+}
+
+template <int HPL, bool LITERAL>
+__device__ __forceinline__ void score_batch(const float (&q)[RB], const float (&hx)[HPL], const float (&hy)[HPL],
+                                            int (&cnt)[HPL], float thresh) {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const float cx = q[u * 4], cy = q[u * 4 + 1], mx = q[u * 4 + 2], my = q[u * 4 + 3];
+#pragma unroll
+        for (int j = 0; j < HPL; ++j) {
+            if (LITERAL) {
+                cnt[j] += inlier_literal(cx, cy, mx, my, hx[j], hy[j], thresh) ? 1 : 0;
+            } else {
+                // 9 VALU ops per (hypothesis, pixel): 2 sub, mul+fma (d.m), mul+fma (|d|^2), mul, cmp, addc.
+                // The compare/accumulate pair is pinned in asm so that it stays v_cmp + v_addc (carry-in = vote).
+                const float dx = hx[j] - cx, dy = hy[j] - cy;
+                const float dot = fmaf(dy, my, dx * mx);
+                const float l2 = fmaf(dy, dy, dx * dx);
+                const float qq = dot * fabsf(dot);
+                asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc"
+                    : "+v"(cnt[j])
+                    : "v"(qq), "v"(l2)
+                    : "vcc");
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K4: inlier scoring                                           (kernel.cu:88-126 + ransac_voting_gpu.py:557-561)
+// ------------------------------------------------------------------------------------------------------------
+template <int HPL, bool LITERAL>
+__global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
+    const int lane = threadIdx.x & 63;
+    const int wave_gid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int nwaves = gridDim.x * 4;
+    const int32_t* __restrict__ ctrl = P.ctrl;
+    const int total = ctrl[P.b * CTRL_STRIDE];
+
+    for (int item = wave_gid; item < total; item += nwaves) {
+        int lo = 0, hi = P.b - 1;  // image owning this item: last bi with item_base[bi] <= item
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (ctrl[mid * CTRL_STRIDE + C_ITEM_BASE] <= item) lo = mid; else hi = mid - 1;
+        }
+        const int bi = lo;
+        const int local = item - ctrl[bi * CTRL_STRIDE + C_ITEM_BASE];
+        const int nch = ctrl[bi * CTRL_STRIDE + C_NCHUNKS];
+        const int tn = ctrl[bi * CTRL_STRIDE + C_TN];
+        const int hg = local % P.hgroups;
+        const int t = local / P.hgroups;
+        const int c = t % nch;
+        const int k = t / nch;
+        const int p0 = c * P.chunk;
+        const int tpad = (tn + PAD - 1) / PAD * PAD;
+        const int p1 = (p0 + P.chunk < tpad) ? p0 + P.chunk : tpad;
+
+        const float2* __restrict__ hb = P.hyp + ((size_t)bi * P.vn + k) * P.hn_pad + (size_t)hg * 64 * HPL;
+        float hx[HPL], hy[HPL];
+        int cnt[HPL];
+#pragma unroll
+        for (int j = 0; j < HPL; ++j) {
+            const float2 hv = hb[j * 64 + lane];
+            hx[j] = hv.x;
+            hy[j] = hv.y;
+            cnt[j] = 0;
+        }
+        // Wave-uniform record stream.  The records were written by an earlier launch and are read-only here;
+        // viewing them through the constant address space makes every load an s_load_dwordx16 into SGPRs
+        // (scalar cache), which the VALU ops take as scalar operands -- no VGPRs, no VMEM issue slots.
+        // Scalar loads return out of order, so the only wait is lgkmcnt(0): the loop therefore (1) waits for
+        // the batch it is about to consume, (2) issues the next batch, (3) computes -- one batch is in flight
+        // for a whole compute phase (several hundred cycles).  The empty asm statements pin that order.
+        const CFloat* r = (const CFloat*)(P.rec + ((size_t)bi * P.vn + k) * P.cap);
+        float A[RB], B[RB];
+        load_batch(r, p0, A);
+        for (int p = p0; p < p1; p += 2 * NB) {  // p1 - p0 is a multiple of PAD = 2 * NB
+            if (!LITERAL) asm volatile("" ::"s"(A[0]), "s"(A[RB - 1]));
+            int pb = p + NB;
+            if (!LITERAL) asm volatile("" : "+s"(pb));
+            load_batch(r, pb, B);
+            if (!LITERAL) __builtin_amdgcn_sched_barrier(0);  // keep the load above the compute phase
+            score_batch<HPL, LITERAL>(A, hx, hy, cnt, P.thresh);
+            if (!LITERAL) asm volatile("" ::"s"(B[0]), "s"(B[RB - 1]));
+            int pa = (p + 2 * NB < p1) ? p + 2 * NB : p;  // last trip re-reads its own batch (discarded)
+            if (!LITERAL) asm volatile("" : "+s"(pa));
+            load_batch(r, pa, A);
+            if (!LITERAL) __builtin_amdgcn_sched_barrier(0);
+            score_batch<HPL, LITERAL>(B, hx, hy, cnt, P.thresh);
+        }
+        uint16_t* __restrict__ po =
+            P.partial + (((size_t)bi * P.vn + k) * P.max_chunks + c) * P.hn_pad + (size_t)hg * 64 * HPL;
+#pragma unroll
+        for (int j = 0; j < HPL; ++j) po[j * 64 + lane] = (uint16_t)cnt[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K5: arg-max + least-squares refinement                        (ransac_voting_gpu.py:561-569, 579-595, 503-512)
+// ------------------------------------------------------------------------------------------------------------
+template <bool LITERAL>
+__global__ __launch_bounds__(256) void select_refine_kernel(VoteParams P) {
+    const int k = blockIdx.x, bi = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t bk = (size_t)bi * P.vn + k;
+    const int nch = P.ctrl[bi * CTRL_STRIDE + C_NCHUNKS];
+    int status = P.ctrl[bi * CTRL_STRIDE + C_STATUS];
+
+    __shared__ unsigned long long s_best[4];
+    __shared__ double s_sum[4][5];
+    __shared__ int s_n[4];
+
+    if (nch == 0) {  // fewer than min_num foreground pixels: zeros (:531-534)
+        if (threadIdx.x < 2) P.out[bk * 2 + threadIdx.x] = 0.f;
+        if (threadIdx.x == 0) {
+            if (P.status) P.status[bk] = status | PVNET_S_SKIPPED;
+            P.win[bk * 2] = 0;
+            P.win[bk * 2 + 1] = 0;
+        }
+        for (int h = threadIdx.x; h < P.hn; h += 256) P.counts[bk * P.hn_pad + h] = 0;
+        return;
+    }
+    // ---- counts = sum over chunks; winner = first maximum (:561-562)
+    unsigned long long best = 0;
+    for (int h = threadIdx.x; h < P.hn; h += 256) {
+        const uint16_t* pp = P.partial + bk * P.max_chunks * P.hn_pad + h;
+        int s = 0;
+        for (int c = 0; c < nch; ++c) s += pp[(size_t)c * P.hn_pad];
+        P.counts[bk * P.hn_pad + h] = s;
+        const unsigned long long key = ((unsigned long long)(uint32_t)s << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)h);
+        best = key > best ? key : best;
+    }
+    best = wave_reduce_max(best);
+    if (lane == 0) s_best[wave] = best;
+    __syncthreads();
+    best = s_best[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) best = s_best[i] > best ? s_best[i] : best;
+    const int wcnt = (int)(best >> 32);
+    const int widx = (int)(0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull));
+    float wx = 0.f, wy = 0.f;  // all_win_pts starts at zero and only a strictly larger ratio replaces it (:548-569)
+    if (wcnt > 0) {
+        const float2 hv = P.hyp[bk * P.hn_pad + widx];
+        wx = hv.x;
+        wy = hv.y;
+    } else {
+        status |= PVNET_S_NO_INLIER;
+    }
+    if (threadIdx.x == 0) {
+        P.win[bk * 2] = widx;
+        P.win[bk * 2 + 1] = wcnt;
+    }
+    if (P.flags & PVNET_F_NO_REFINE) {
+        if (threadIdx.x == 0) {
+            P.out[bk * 2] = wx;
+            P.out[bk * 2 + 1] = wy;
+            if (P.status) P.status[bk] = status;
+        }
+        return;
+    }
+    // ---- inliers of the winner, normal equations centred on the winner, float64 (:579-594)
+    const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
+    double a = 0, bb = 0, d = 0, r0 = 0, r1 = 0;
+    int n = 0;
+    for (int t = threadIdx.x; t < tn; t += 256) {
+        const float4 q = P.rec[bk * P.cap + t];
+        const float2 u = P.dir[bk * P.cap + t];
+        const bool in = LITERAL ? inlier_literal(q.x, q.y, u.x, u.y, wx, wy, P.thresh)
+                                : inlier_fast(q.x, q.y, q.z, q.w, wx, wy);
+        if (in) {
+            const double nx = (double)u.y, ny = -(double)u.x;  // normal = (dy, -dx) (:580-581)
+            const double bv = nx * ((double)q.x - (double)wx) + ny * ((double)q.y - (double)wy);
+            a += nx * nx;
+            bb += nx * ny;
+            d += ny * ny;
+            r0 += nx * bv;
+            r1 += ny * bv;
+            ++n;
+        }
+    }
+    a = wave_reduce_add(a);
+    bb = wave_reduce_add(bb);
+    d = wave_reduce_add(d);
+    r0 = wave_reduce_add(r0);
+    r1 = wave_reduce_add(r1);
+    n = wave_reduce_add(n);
+    if (lane == 0) {
+        s_sum[wave][0] = a; s_sum[wave][1] = bb; s_sum[wave][2] = d; s_sum[wave][3] = r0; s_sum[wave][4] = r1;
+        s_n[wave] = n;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = bb = d = r0 = r1 = 0;
+        n = 0;
+        for (int i = 0; i < 4; ++i) {
+            a += s_sum[i][0]; bb += s_sum[i][1]; d += s_sum[i][2]; r0 += s_sum[i][3]; r1 += s_sum[i][4];
+            n += s_n[i];
+        }
+        const double det = a * d - bb * bb;
+        float ox = wx, oy = wy;
+        if (n == 0 || det == 0.0 || !isfinite(det)) {
+            status |= PVNET_S_SINGULAR;  // torch.gesv raises here (:511); we return the winner and flag it
+        } else {
+            ox = (float)((double)wx + (d * r0 - bb * r1) / det);
+            oy = (float)((double)wy + (a * r1 - bb * r0) / det);
+        }
+        P.out[bk * 2] = ox;
+        P.out[bk * 2 + 1] = oy;
+        if (P.status) P.status[bk] = status;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// op-level kernels with the reference extension's layouts
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void op_generate_hypothesis_kernel(const float* __restrict__ direct,
+                                                                     const float* __restrict__ coords,
+                                                                     const int32_t* __restrict__ idxs,
+                                                                     float* __restrict__ hyp, int tn, int vn, int hn) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= hn * vn) return;
+    const int k = i % vn;
+    int t0 = idxs[i * 2], t1 = idxs[i * 2 + 1];
+    t0 = t0 < 0 ? 0 : (t0 >= tn ? tn - 1 : t0);
+    t1 = t1 < 0 ? 0 : (t1 >= tn ? tn - 1 : t1);
+    float ox, oy;
+    hyp_intersect(direct[((size_t)t0 * vn + k) * 2], direct[((size_t)t0 * vn + k) * 2 + 1], coords[t0 * 2],
+                  coords[t0 * 2 + 1], direct[((size_t)t1 * vn + k) * 2], direct[((size_t)t1 * vn + k) * 2 + 1],
+                  coords[t1 * 2], coords[t1 * 2 + 1], ox, oy);
+    hyp[i * 2] = ox;
+    hyp[i * 2 + 1] = oy;
+}
+
+// grid (ceil(tn/256), vn, hyp-slices): lane owns a pixel, walks a slice of hypotheses (wave-uniform -> SGPRs),
+// byte stores along tn are contiguous per hypothesis row.
+__global__ __launch_bounds__(256) void op_voting_kernel(const float* __restrict__ direct,
+                                                        const float* __restrict__ coords,
+                                                        const float* __restrict__ hyp, uint8_t* __restrict__ inliers,
+                                                        int tn, int vn, int hn, float thresh, int hslice) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    const int h0 = blockIdx.z * hslice;
+    const int h1 = h0 + hslice < hn ? h0 + hslice : hn;
+    if (t >= tn) return;
+    const float cx = coords[t * 2], cy = coords[t * 2 + 1];
+    const float nx = direct[((size_t)t * vn + k) * 2], ny = direct[((size_t)t * vn + k) * 2 + 1];
+    for (int h = h0; h < h1; ++h) {
+        const float hx = hyp[((size_t)h * vn + k) * 2], hy = hyp[((size_t)h * vn + k) * 2 + 1];
+        if (inlier_literal(cx, cy, nx, ny, hx, hy, thresh)) inliers[((size_t)h * vn + k) * tn + t] = 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+int num_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
+#define PV_LAUNCH_CHECK()                                   \
+    do {                                                    \
+        hipError_t e_ = hipGetLastError();                  \
+        if (e_ != hipSuccess) return (int)e_;               \
+    } while (0)
+#define PV_HIP(x)                                           \
+    do {                                                    \
+        hipError_t e_ = (x);                                \
+        if (e_ != hipSuccess) return (int)e_;               \
+    } while (0)
+
+template <bool LITERAL>
+int launch_score(const VoteParams& P, dim3 grid, hipStream_t s) {
+    switch (P.hpl) {
+        case 1: hipLaunchKernelGGL((score_kernel<1, LITERAL>), grid, dim3(256), 0, s, P); break;
+        case 2: hipLaunchKernelGGL((score_kernel<2, LITERAL>), grid, dim3(256), 0, s, P); break;
+        case 4: hipLaunchKernelGGL((score_kernel<4, LITERAL>), grid, dim3(256), 0, s, P); break;
+        case 8: hipLaunchKernelGGL((score_kernel<8, LITERAL>), grid, dim3(256), 0, s, P); break;
+        default: return PVNET_E_UNSUPPORTED;
+    }
+    return 0;
+}
+
+int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
+    const bool literal = (P.flags & PVNET_F_LITERAL) != 0;
+    auto mark = [&](int i) -> hipError_t { return ev ? hipEventRecord(ev[i], s) : hipSuccess; };
+    PV_HIP(hipMemsetAsync(P.ctrl, 0, sizeof(int32_t) * CTRL_STRIDE * (size_t)(P.b + 1), s));
+    PV_HIP(mark(0));
+    {   // K1
+        const int wpb = 4 * K1_WORDS_PER_WAVE;
+        dim3 grid((P.words + wpb - 1) / wpb, P.b);
+        switch (P.mask_dtype) {
+            case PVNET_MASK_U8: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_U8>, grid, dim3(256), 0, s, P); break;
+            case PVNET_MASK_I16: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I16>, grid, dim3(256), 0, s, P); break;
+            case PVNET_MASK_I32: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I32>, grid, dim3(256), 0, s, P); break;
+            case PVNET_MASK_I64: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I64>, grid, dim3(256), 0, s, P); break;
+            case PVNET_MASK_F32: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_F32>, grid, dim3(256), 0, s, P); break;
+            default: return PVNET_E_BADARG;
+        }
+        PV_LAUNCH_CHECK();
+        PV_HIP(mark(1));
+        if (P.max_num < P.npix) {  // host-known: subsampling can only trigger when max_num < h*w
+            hipLaunchKernelGGL(subsample_kernel, grid, dim3(256), 0, s, P);
+            PV_LAUNCH_CHECK();
+        }
+        PV_HIP(mark(2));
+    }
+    {   // K2
+        dim3 grid((P.words + K2_WORDS_PER_BLOCK - 1) / K2_WORDS_PER_BLOCK, P.b);
+        if (literal) hipLaunchKernelGGL(compact_kernel<true>, grid, dim3(256), 0, s, P);
+        else hipLaunchKernelGGL(compact_kernel<false>, grid, dim3(256), 0, s, P);
+        PV_LAUNCH_CHECK();
+        PV_HIP(mark(3));
+    }
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(256), 0, s, P);
+    PV_LAUNCH_CHECK();
+    PV_HIP(mark(4));
+    {   // K3
+        dim3 grid((P.hn * P.vn + 255) / 256, P.b);
+        hipLaunchKernelGGL(hypothesis_kernel, grid, dim3(256), 0, s, P);
+        PV_LAUNCH_CHECK();
+        PV_HIP(mark(5));
+    }
+    {   // K4: persistent grid, work items strided over its waves
+        const long long max_items = (long long)P.b * P.vn * P.hgroups * P.max_chunks;
+        const int wgs_per_cu = env_int("PVNET_SCORE_WGS_PER_CU", 4);
+        long long wgs = (long long)num_cus() * wgs_per_cu;
+        if (wgs > (max_items + 3) / 4) wgs = (max_items + 3) / 4;
+        if (wgs < 1) wgs = 1;
+        int rc = literal ? launch_score<true>(P, dim3((unsigned)wgs), s) : launch_score<false>(P, dim3((unsigned)wgs), s);
+        if (rc) return rc;
+        PV_LAUNCH_CHECK();
+        PV_HIP(mark(6));
+    }
+    {   // K5
+        dim3 grid(P.vn, P.b);
+        if (literal) hipLaunchKernelGGL(select_refine_kernel<true>, grid, dim3(256), 0, s, P);
+        else hipLaunchKernelGGL(select_refine_kernel<false>, grid, dim3(256), 0, s, P);
+        PV_LAUNCH_CHECK();
+        PV_HIP(mark(7));
+    }
+    return 0;
+}
+
+int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* ms, const float* vertex,
+                const int64_t* vs, int b, int h, int w, int vn, int hn, float thresh, int min_num, int max_num,
+                uint64_t seed, const int32_t* idxs, uint32_t flags, float* out, int32_t* status, void* ws,
+                size_t ws_bytes) {
+    if (!mask || !vertex || !ms || !vs || !out || !ws) return PVNET_E_BADARG;
+    if (mask_dtype < PVNET_MASK_U8 || mask_dtype > PVNET_MASK_F32) return PVNET_E_BADARG;
+    PvnetVoteLayout L;
+    int rc = pvnet_vote_layout(b, h, w, vn, hn, max_num, &L);
+    if (rc) return rc;
+    if (ws_bytes < L.total_bytes) return PVNET_E_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(ws) & 255u) != 0) return PVNET_E_BADARG;
+    // the sqrt-free predicate folds 1/thresh into the records: needs thresh > 0; otherwise score literally
+    if (!(thresh > 0.f)) flags |= PVNET_F_LITERAL;
+    char* base = static_cast<char*>(ws);
+    P.mask = mask; P.ms0 = ms[0]; P.ms1 = ms[1]; P.ms2 = ms[2];
+    P.mask_dtype = mask_dtype;
+    P.mask_linear = (ms[2] == 1 && ms[1] == w) ? 1 : 0;
+    P.vertex = vertex; P.vs0 = vs[0]; P.vs1 = vs[1]; P.vs2 = vs[2]; P.vs3 = vs[3]; P.vs4 = vs[4];
+    P.b = b; P.h = h; P.w = w; P.vn = vn; P.hn = hn; P.npix = h * w;
+    P.words = L.words; P.cap = L.cap; P.chunk = L.chunk; P.max_chunks = L.max_chunks;
+    P.hpl = L.hpl; P.hgroups = L.hgroups; P.hn_pad = L.hn_pad;
+    P.thresh = thresh; P.min_num = min_num; P.max_num = max_num; P.seed = seed; P.idxs = idxs; P.flags = flags;
+    P.ctrl = reinterpret_cast<int32_t*>(base + L.off_ctrl);
+    P.bits = reinterpret_cast<uint64_t*>(base + L.off_bits);
+    P.pix = reinterpret_cast<int32_t*>(base + L.off_pix);
+    P.rec = reinterpret_cast<float4*>(base + L.off_rec);
+    P.dir = reinterpret_cast<float2*>(base + L.off_dir);
+    P.hyp = reinterpret_cast<float2*>(base + L.off_hyp);
+    P.partial = reinterpret_cast<uint16_t*>(base + L.off_partial);
+    P.counts = reinterpret_cast<int32_t*>(base + L.off_counts);
+    P.win = reinterpret_cast<int32_t*>(base + L.off_win);
+    P.out = out; P.status = status;
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int pvnet_vote_abi_version(void) { return PVNET_VOTE_ABI_VERSION; }
+const char* pvnet_vote_build_info(void) { return "pvnet_vote gfx950 hip " __DATE__ " " __TIME__; }
+
+int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVoteLayout* L) {
+    if (!L || b <= 0 || h <= 0 || w <= 0 || vn <= 0 || hn <= 0 || max_num < 0) return PVNET_E_BADARG;
+    if ((long long)h * w > (1ll << 30) || b > 65535 || vn > 65535 || hn > (1 << 20)) return PVNET_E_UNSUPPORTED;
+    const long long npix = (long long)h * w;
+    long long cap = npix;
+    if (max_num < npix) {  // tn ~ Binomial(tn0, max_num/tn0): mean max_num, sigma <= sqrt(max_num); 8 sigma margin
+        const long long c = (long long)max_num + 8ll * (long long)ceil(sqrt((double)max_num)) + 64;
+        cap = c < npix ? c : npix;
+    }
+    cap = (cap + PAD - 1) / PAD * PAD + PAD;
+    int hpl = hn >= 512 ? 4 : (hn >= 128 ? 2 : 1);
+    hpl = env_int("PVNET_SCORE_HPL", hpl);
+    if (hpl != 1 && hpl != 2 && hpl != 4 && hpl != 8) return PVNET_E_UNSUPPORTED;
+    const int hgroups = (hn + 64 * hpl - 1) / (64 * hpl);
+    const long long units = (long long)b * vn * hgroups;
+    int chunk = units >= 512 ? 256 : (units >= 128 ? 128 : 64);
+    chunk = env_int("PVNET_SCORE_CHUNK", chunk);
+    if (chunk < PAD || chunk % PAD != 0 || chunk > 65528) return PVNET_E_UNSUPPORTED;
+    L->b = b; L->h = h; L->w = w; L->vn = vn; L->hn = hn;
+    L->cap = (int)cap;
+    L->words = (int)((npix + 63) / 64);
+    L->chunk = chunk;
+    L->max_chunks = (int)((cap + chunk - 1) / chunk);
+    L->hpl = hpl;
+    L->hgroups = hgroups;
+    L->hn_pad = hgroups * 64 * hpl;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L->off_ctrl = take(sizeof(int32_t) * CTRL_STRIDE * (size_t)(b + 1));
+    L->off_bits = take(sizeof(uint64_t) * (size_t)b * L->words);
+    L->off_pix = take(sizeof(int32_t) * (size_t)b * cap);
+    L->off_rec = take(sizeof(float) * 4 * (size_t)b * vn * cap);
+    L->off_dir = take(sizeof(float) * 2 * (size_t)b * vn * cap);
+    L->off_hyp = take(sizeof(float) * 2 * (size_t)b * vn * L->hn_pad);
+    L->off_partial = take(sizeof(uint16_t) * (size_t)b * vn * L->max_chunks * L->hn_pad);
+    L->off_counts = take(sizeof(int32_t) * (size_t)b * vn * L->hn_pad);
+    L->off_win = take(sizeof(int32_t) * 2 * (size_t)b * vn);
+    L->total_bytes = off;
+    return 0;
+}
+
+size_t pvnet_vote_workspace_bytes(int b, int h, int w, int vn, int hn, int max_num) {
+    PvnetVoteLayout L;
+    return pvnet_vote_layout(b, h, w, vn, hn, max_num, &L) == 0 ? L.total_bytes : 0;
+}
+
+int pvnet_vote_v3(const void* mask, int mask_dtype, const int64_t mask_strides[3], const float* vertex,
+                  const int64_t vertex_strides[5], int b, int h, int w, int vn, int hn, float inlier_thresh,
+                  int min_num, int max_num, uint64_t seed, const int32_t* idxs, uint32_t flags, float* out_kpts,
+                  int32_t* out_status, void* workspace, size_t workspace_bytes, void* stream) {
+    VoteParams P;
+    int rc = fill_params(P, mask, mask_dtype, mask_strides, vertex, vertex_strides, b, h, w, vn, hn, inlier_thresh,
+                         min_num, max_num, seed, idxs, flags, out_kpts, out_status, workspace, workspace_bytes);
+    if (rc) return rc;
+    return launch_all(P, static_cast<hipStream_t>(stream), nullptr);
+}
+
+int pvnet_vote_v3_profiled(const void* mask, int mask_dtype, const int64_t mask_strides[3], const float* vertex,
+                           const int64_t vertex_strides[5], int b, int h, int w, int vn, int hn,
+                           float inlier_thresh, int min_num, int max_num, uint64_t seed, const int32_t* idxs,
+                           uint32_t flags, float* out_kpts, int32_t* out_status, void* workspace,
+                           size_t workspace_bytes, void* stream, float* stage_ms) {
+    if (!stage_ms) return PVNET_E_BADARG;
+    VoteParams P;
+    int rc = fill_params(P, mask, mask_dtype, mask_strides, vertex, vertex_strides, b, h, w, vn, hn, inlier_thresh,
+                         min_num, max_num, seed, idxs, flags, out_kpts, out_status, workspace, workspace_bytes);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipEvent_t ev[PVNET_NUM_STAGES + 1];
+    int created = 0;
+    for (; created <= PVNET_NUM_STAGES; ++created)
+        if (hipEventCreate(&ev[created]) != hipSuccess) break;
+    if (created <= PVNET_NUM_STAGES) {
+        for (int i = 0; i < created; ++i) (void)hipEventDestroy(ev[i]);
+        return (int)hipErrorOutOfMemory;
+    }
+    rc = launch_all(P, s, ev);
+    hipError_t e = hipStreamSynchronize(s);
+    if (rc == 0 && e != hipSuccess) rc = (int)e;
+    if (rc == 0)
+        for (int i = 0; i < PVNET_NUM_STAGES; ++i) {
+            float ms = 0.f;
+            e = hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            stage_ms[i] = (e == hipSuccess) ? ms : -1.f;
+        }
+    for (int i = 0; i <= PVNET_NUM_STAGES; ++i) (void)hipEventDestroy(ev[i]);
+    return rc;
+}
+
+int pvnet_generate_hypothesis(const float* direct, const float* coords, const int32_t* idxs, float* hypo_pts, int tn,
+                              int vn, int hn, void* stream) {
+    if (!direct || !coords || !idxs || !hypo_pts || tn <= 0 || vn <= 0 || hn <= 0) return PVNET_E_BADARG;
+    hipLaunchKernelGGL(op_generate_hypothesis_kernel, dim3((hn * vn + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), direct, coords, idxs, hypo_pts, tn, vn, hn);
+    PV_LAUNCH_CHECK();
+    return 0;
+}
+
+int pvnet_voting_for_hypothesis(const float* direct, const float* coords, const float* hypo_pts, uint8_t* inliers,
+                                int tn, int vn, int hn, float inlier_thresh, void* stream) {
+    if (!direct || !coords || !hypo_pts || !inliers || tn <= 0 || vn <= 0 || hn <= 0) return PVNET_E_BADARG;
+    if (vn > 65535) return PVNET_E_UNSUPPORTED;
+    const int tblocks = (tn + 255) / 256;
+    int slices = (2048 + tblocks * vn - 1) / (tblocks * vn);  // aim for >= 2048 blocks
+    if (slices > hn) slices = hn;
+    if (slices > 65535) slices = 65535;
+    if (slices < 1) slices = 1;
+    const int hslice = (hn + slices - 1) / slices;
+    slices = (hn + hslice - 1) / hslice;
+    hipLaunchKernelGGL(op_voting_kernel, dim3(tblocks, vn, slices), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       direct, coords, hypo_pts, inliers, tn, vn, hn, inlier_thresh, hslice);
+    PV_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,265 @@
+"""Host-side mirror of the reference's voting-layer interface on top of the C-ABI HIP library.
+
+Mirrors (same names, argument meaning, defaults and error behaviour):
+
+* ``ransac_voting_layer_v3``  -- lib/ransac_voting_gpu_layer/ransac_voting_gpu.py:514-598
+* ``generate_hypothesis`` / ``voting_for_hypothesis`` ops -- lib/ransac_voting_gpu_layer/src/ransac_voting.cpp:20-55,
+  exported by the pybind module ``ransac_voting`` (:102-107)
+
+PyTorch is plumbing only here: device memory, the current stream, dtype/stride bookkeeping.  All compute is
+in ``libpvnet_vote.so`` (pvnet_amd/csrc/pvnet_vote.hip, C ABI in include/pvnet_vote.h) reached through ctypes
+(which releases the GIL for the duration of the call).  There is NO CPU fallback: without the library, or with
+CPU tensors, these functions raise ``RuntimeError`` exactly like the reference's ``CHECK_CUDA`` does
+(src/ransac_voting.cpp:7-9).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpvnet_vote.so")
+
+F_LITERAL = 1
+F_NO_REFINE = 2
+S_SKIPPED, S_SINGULAR, S_NO_INLIER, S_OVERFLOW = 1, 2, 4, 8
+NUM_STAGES = 7
+STAGE_NAMES = ("mask_bits", "subsample", "compact", "plan", "hypotheses", "score", "select_refine")
+
+
+class Layout(C.Structure):
+    """ctypes image of ``PvnetVoteLayout`` (include/pvnet_vote.h)."""
+    _fields_ = [(n, C.c_int32) for n in ("b", "h", "w", "vn", "hn", "cap", "words", "chunk", "max_chunks", "hpl",
+                                          "hgroups", "hn_pad")] + \
+               [(n, C.c_size_t) for n in ("off_ctrl", "off_bits", "off_pix", "off_rec", "off_dir", "off_hyp",
+                                          "off_partial", "off_counts", "off_win", "total_bytes")]
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the in-tree HIP library; loud failure if it has not been built (python -m pvnet_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"pvnet_amd: HIP library {LIB_PATH} is missing -- build it with "
+                           f"`python -m pvnet_amd.build` (hipcc, gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    i64p, f32p, i32p, u8p = C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p
+    lib.pvnet_vote_abi_version.restype = C.c_int
+    lib.pvnet_vote_build_info.restype = C.c_char_p
+    lib.pvnet_vote_layout.restype = C.c_int
+    lib.pvnet_vote_layout.argtypes = [C.c_int] * 6 + [C.POINTER(Layout)]
+    lib.pvnet_vote_workspace_bytes.restype = C.c_size_t
+    lib.pvnet_vote_workspace_bytes.argtypes = [C.c_int] * 6
+    v3_args = [C.c_void_p, C.c_int, i64p, f32p, i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+               C.c_int, C.c_int, C.c_uint64, i32p, C.c_uint32, f32p, i32p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.pvnet_vote_v3.restype = C.c_int
+    lib.pvnet_vote_v3.argtypes = v3_args
+    lib.pvnet_vote_v3_profiled.restype = C.c_int
+    lib.pvnet_vote_v3_profiled.argtypes = v3_args + [C.POINTER(C.c_float)]
+    lib.pvnet_generate_hypothesis.restype = C.c_int
+    lib.pvnet_generate_hypothesis.argtypes = [f32p, f32p, i32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.pvnet_voting_for_hypothesis.restype = C.c_int
+    lib.pvnet_voting_for_hypothesis.argtypes = [f32p, f32p, f32p, u8p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                                C.c_void_p]
+    if lib.pvnet_vote_abi_version() != 1:
+        raise RuntimeError("pvnet_amd: libpvnet_vote.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc == 0:
+        return
+    names = {-1: "PVNET_E_BADARG", -2: "PVNET_E_WORKSPACE", -3: "PVNET_E_UNSUPPORTED"}
+    raise RuntimeError(f"{what} failed: {names.get(rc, 'hipError_t ' + str(rc))}")
+
+
+_MASK_CODES = {torch.uint8: 0, torch.int8: 0, torch.bool: 0, torch.int16: 1, torch.int32: 2, torch.int64: 3,
+               torch.float32: 4}
+
+
+def vote_layout(b, h, w, vn, hn, max_num) -> Layout:
+    L = Layout()
+    _check(load_library().pvnet_vote_layout(b, h, w, vn, hn, max_num, C.byref(L)), "pvnet_vote_layout")
+    return L
+
+
+def _prepare(mask, vertex, round_hyp_num, max_num, idxs):
+    if not (isinstance(mask, torch.Tensor) and isinstance(vertex, torch.Tensor)):
+        raise TypeError("mask and vertex must be torch tensors")
+    if not vertex.is_cuda:
+        raise RuntimeError("vertex must be a CUDA tensor")  # CHECK_CUDA, ransac_voting.cpp:7
+    if not mask.is_cuda:
+        raise RuntimeError("mask must be a CUDA tensor")
+    if mask.device != vertex.device:
+        raise RuntimeError("mask and vertex must live on the same device")
+    if vertex.dim() != 5 or vertex.shape[-1] != 2:
+        raise RuntimeError(f"vertex must be [b,h,w,vn,2], got {tuple(vertex.shape)}")
+    b, h, w, vn, _ = vertex.shape
+    if tuple(mask.shape) != (b, h, w):
+        raise RuntimeError(f"mask must be [b,h,w]={(b, h, w)}, got {tuple(mask.shape)}")
+    if vertex.dtype != torch.float32:
+        vertex = vertex.float()
+    if mask.dtype not in _MASK_CODES:
+        mask = mask.float()  # .byte() of any other float type truncates the same way
+    hn = int(round_hyp_num)
+    if hn <= 0:
+        raise RuntimeError("round_hyp_num must be positive")
+    max_num = int(min(max(int(max_num), 0), 2 ** 31 - 1))
+    if idxs is not None:
+        if not idxs.is_cuda or idxs.device != vertex.device:
+            raise RuntimeError("idxs must be a CUDA tensor on the inputs' device")
+        if idxs.dim() == 3:
+            idxs = idxs.unsqueeze(0).expand(b, -1, -1, -1)
+        if tuple(idxs.shape) != (b, hn, vn, 2):
+            raise RuntimeError(f"idxs must be [b,hn,vn,2]={(b, hn, vn, 2)}, got {tuple(idxs.shape)}")
+        idxs = idxs.to(torch.int32).contiguous()
+    return mask, vertex, b, h, w, vn, hn, max_num, idxs
+
+
+def _strides(t, n):
+    return (C.c_int64 * n)(*[int(s) for s in t.stride()])
+
+
+def _debug_views(ws: torch.Tensor, L: Layout):
+    """typed views into the workspace (see PvnetVoteLayout) for tests / visualisation."""
+    def view(off, nbytes, dtype, shape):
+        return ws[off:off + nbytes].view(dtype).view(*shape)
+    b, vn, cap, hp = L.b, L.vn, L.cap, L.hn_pad
+    ctrl = view(L.off_ctrl, 4 * 8 * (b + 1), torch.int32, (b + 1, 8))
+    return dict(
+        layout=L, ctrl=ctrl, tn0=ctrl[:b, 0], tn=ctrl[:b, 1], nchunks=ctrl[:b, 4], total_items=ctrl[b, 0],
+        bits=view(L.off_bits, 8 * b * L.words, torch.int64, (b, L.words)),
+        pix=view(L.off_pix, 4 * b * cap, torch.int32, (b, cap)),
+        rec=view(L.off_rec, 16 * b * vn * cap, torch.float32, (b, vn, cap, 4)),
+        dir=view(L.off_dir, 8 * b * vn * cap, torch.float32, (b, vn, cap, 2)),
+        hyp=view(L.off_hyp, 8 * b * vn * hp, torch.float32, (b, vn, hp, 2))[:, :, :L.hn],
+        counts=view(L.off_counts, 4 * b * vn * hp, torch.int32, (b, vn, hp))[:, :, :L.hn],
+        win=view(L.off_win, 8 * b * vn, torch.int32, (b, vn, 2)),
+    )
+
+
+def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99, max_iter=20,
+                           min_num=5, max_num=30000, *, idxs: Optional[torch.Tensor] = None,
+                           seed: Optional[int] = None, literal: bool = False, refine: bool = True,
+                           return_status: bool = False, return_debug: bool = False, stage_times: bool = False):
+    """Drop-in for the reference's ``ransac_voting_layer_v3`` (ransac_voting_gpu.py:514-598).
+
+    :param mask:      [b,h,w]  any integer / bool / float dtype; foreground <=> ``mask.byte() != 0``
+    :param vertex:    [b,h,w,vn,2] float32, any strides (the planar permuted view of tools/demo.py:48-50 is
+                      read in place, never copied)
+    :param round_hyp_num: hypotheses per key-point
+    :param inlier_thresh, min_num, max_num: as the reference
+    :param confidence, max_iter: accepted and ignored -- the reference re-uses one ``idxs`` draw for every round
+                      (:547 is outside the loop at :552), so rounds after the first never change its result.
+    :return: [b,vn,2] float32 on ``mask.device``
+
+    Extra keyword-only arguments (never required):
+      idxs    int tensor [b,hn,vn,2] (or [hn,vn,2]): pixel-pair indices into each image's raster-ordered
+              foreground list, replacing the internal counter RNG (parity runs against the oracle)
+      seed    RNG seed (default: drawn from torch's CPU generator, so ``torch.manual_seed`` makes runs repeatable)
+      literal score with the reference's float32 operation order (bit-exact with the float32 oracle, slower)
+      refine  False skips the least-squares refinement (:579-595) and returns the winning hypotheses
+      return_status / return_debug / stage_times: also return the per-(image,kp) status bits / typed views of
+              the workspace / per-stage GPU milliseconds (synchronises; for bench.py)
+    """
+    lib = load_library()
+    mask, vertex, b, h, w, vn, hn, max_num, idxs = _prepare(mask, vertex, round_hyp_num, max_num, idxs)
+    dev = vertex.device
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    flags = (F_LITERAL if literal else 0) | (0 if refine else F_NO_REFINE)
+    L = vote_layout(b, h, w, vn, hn, max_num)
+    with torch.cuda.device(dev):
+        ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=dev)
+        out = torch.empty((b, vn, 2), dtype=torch.float32, device=dev)
+        status = torch.empty((b, vn), dtype=torch.int32, device=dev) if (return_status or return_debug) else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        args = [C.c_void_p(mask.data_ptr()), _MASK_CODES[mask.dtype], _strides(mask, 3),
+                C.c_void_p(vertex.data_ptr()), _strides(vertex, 5), b, h, w, vn, hn, C.c_float(inlier_thresh),
+                int(min_num), max_num, C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF),
+                C.c_void_p(idxs.data_ptr()) if idxs is not None else None, flags, C.c_void_p(out.data_ptr()),
+                C.c_void_p(status.data_ptr()) if status is not None else None, C.c_void_p(ws.data_ptr()),
+                C.c_size_t(L.total_bytes), C.c_void_p(stream)]
+        times = None
+        if stage_times:
+            ms = (C.c_float * NUM_STAGES)()
+            _check(lib.pvnet_vote_v3_profiled(*args, ms), "pvnet_vote_v3_profiled")
+            times = dict(zip(STAGE_NAMES, [float(x) for x in ms]))
+        else:
+            _check(lib.pvnet_vote_v3(*args), "pvnet_vote_v3")
+    extras = []
+    if return_status:
+        extras.append(status)
+    if return_debug:
+        d = _debug_views(ws, L)
+        d["status"] = status
+        d["seed"] = seed
+        extras.append(d)
+    if stage_times:
+        extras.append(times)
+    return (out, *extras) if extras else out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# op-level functions of the reference's pybind module `ransac_voting` (src/ransac_voting.cpp:102-107)
+# ---------------------------------------------------------------------------------------------------------
+def _check_input(x, name, dtype):
+    if not x.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")  # CHECK_CUDA
+    if not x.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")  # CHECK_CONTIGUOUS
+    if x.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}")  # implicit in .data<T>() of the reference
+
+
+def generate_hypothesis(direct, coords, idxs):
+    """direct [tn,vn,2] f32, coords [tn,2] f32, idxs [hn,vn,2] i32 -> new [hn,vn,2] f32 (ransac_voting.cpp:20-31)."""
+    _check_input(direct, "direct", torch.float32)
+    _check_input(coords, "coords", torch.float32)
+    _check_input(idxs, "idxs", torch.int32)
+    tn, vn, _ = direct.shape
+    hn = idxs.shape[0]
+    if coords.shape != (tn, 2) or idxs.shape != (hn, vn, 2) or direct.shape[2] != 2:
+        raise RuntimeError("generate_hypothesis: shape mismatch")
+    out = torch.empty((hn, vn, 2), dtype=torch.float32, device=direct.device)
+    with torch.cuda.device(direct.device):
+        _check(load_library().pvnet_generate_hypothesis(
+            C.c_void_p(direct.data_ptr()), C.c_void_p(coords.data_ptr()), C.c_void_p(idxs.data_ptr()),
+            C.c_void_p(out.data_ptr()), tn, vn, hn, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            "pvnet_generate_hypothesis")
+    return out
+
+
+def voting_for_hypothesis(direct, coords, hypo_pts, inliers, inlier_thresh):
+    """in place: inliers [hn,vn,tn] uint8 gets a 1 wherever the pixel votes (ransac_voting.cpp:41-55)."""
+    _check_input(direct, "direct", torch.float32)
+    _check_input(coords, "coords", torch.float32)
+    _check_input(hypo_pts, "hypo_pts", torch.float32)
+    _check_input(inliers, "inliers", torch.uint8)
+    tn, vn, _ = direct.shape
+    hn = hypo_pts.shape[0]
+    if coords.shape != (tn, 2) or hypo_pts.shape != (hn, vn, 2) or inliers.shape != (hn, vn, tn):
+        raise RuntimeError("voting_for_hypothesis: shape mismatch")
+    with torch.cuda.device(direct.device):
+        _check(load_library().pvnet_voting_for_hypothesis(
+            C.c_void_p(direct.data_ptr()), C.c_void_p(coords.data_ptr()), C.c_void_p(hypo_pts.data_ptr()),
+            C.c_void_p(inliers.data_ptr()), tn, vn, hn, C.c_float(inlier_thresh),
+            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "pvnet_voting_for_hypothesis")
+    return None
+
+
+def generate_hypothesis_vanishing_point(*_a, **_k):
+    raise NotImplementedError("vanishing-point ops are out of scope (their only caller in the reference, "
+                              "ransac_voting_gpu.py:408-501, references undefined names) -- SURVEY.md section 2")
+
+
+def voting_for_hypothesis_vanishing_point(*_a, **_k):
+    raise NotImplementedError("vanishing-point ops are out of scope -- SURVEY.md section 2")

@@ -1,0 +1,297 @@
+"""GPU parity tests: the HIP voting layer (through the C ABI) against the CPU oracle on identical inputs.
+
+Bars (north_star): integer products -- compacted pixel lists, inlier counts, winner indices -- bit-exact in
+literal mode; key-points within 1e-3 px of the float64 oracle (tolerance written at each assert)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+from oracle import ransac_voting_oracle as O
+from pvnet_amd import synth, voting
+
+pytestmark = pytest.mark.gpu
+
+TOL_PX = 1e-3  # north_star: key-points within 1e-3 px of the reference on identical inputs
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def to_dev(mask, planar, mask_dtype=None):
+    m = torch.from_numpy(np.ascontiguousarray(mask)).to(dev())
+    if mask_dtype is not None:
+        m = m.to(mask_dtype)
+    p = torch.from_numpy(planar).to(dev())
+    return m, synth.planar_to_vertex_view(p)
+
+
+def small_batch(b=2, first=500, h=240, w=320, radius=22, noise=True, background="normal"):
+    mask, planar, kpts = synth.make_batch(b, first_index=first, h=h, w=w, radius=radius, noise=noise,
+                                          background=background)
+    return mask, planar, kpts, synth.planar_to_vertex_view(planar)
+
+
+# ------------------------------------------------------------------------------------------------ G1
+@pytest.mark.parametrize("literal", [False, True])
+def test_demo_fixture(demo_fixture, literal):
+    mask = demo_fixture["mask"]
+    planar = synth.field_from_keypoints(mask.astype(bool), demo_fixture["points_2d"])
+    m, v = to_dev(mask[None].astype(np.int64), planar[None])
+    assert not v.is_contiguous()  # the strided view of tools/demo.py:48-50 is consumed in place
+    out, dbg = voting.ransac_voting_layer_v3(m, v, 512, inlier_thresh=0.99, literal=literal, return_debug=True)
+    out = out.cpu().numpy()
+    assert int(dbg["tn"][0]) == 2289
+    assert (dbg["win"][0, :, 1].cpu().numpy() == 2289).all()  # clean field: the winner collects every pixel
+    assert np.abs(out[0] - demo_fixture["points_2d"]).max() < TOL_PX
+    o64 = O.ransac_voting_layer_v3(mask[None], synth.planar_to_vertex_view(planar[None]), 512, inlier_thresh=0.99)
+    assert np.abs(out - o64).max() < TOL_PX
+
+
+# ------------------------------------------------------------------------------------------------ compaction
+def test_compaction_order_and_vectors():
+    mask, planar, _, vnp = small_batch(b=3, h=101, w=173, radius=17)
+    mask[2, :, :] = 0
+    mask[2, 50, 3:9] = 1
+    m, v = to_dev(mask, planar)
+    _, dbg = voting.ransac_voting_layer_v3(m, v, 64, inlier_thresh=0.99, seed=1, return_debug=True)
+    for bi in range(3):
+        fg = O.foreground(mask[bi])
+        coords, direct = O.compact(fg, vnp[bi])
+        tn = int(dbg["tn"][bi])
+        assert tn == coords.shape[0] == int(dbg["tn0"][bi])
+        pix = dbg["pix"][bi, :tn].cpu().numpy()
+        np.testing.assert_array_equal(pix, (coords[:, 1] * 173 + coords[:, 0]).astype(np.int64))  # raster order
+        d = dbg["dir"][bi, :, :tn].cpu().numpy()  # [vn,tn,2]
+        np.testing.assert_array_equal(d.transpose(1, 0, 2), direct)
+        rec = dbg["rec"][bi, :, :tn].cpu().numpy()
+        np.testing.assert_array_equal(rec[0, :, 0], coords[:, 0])
+        np.testing.assert_array_equal(rec[0, :, 1], coords[:, 1])
+
+
+# ------------------------------------------------------------------------------------------------ literal mode
+@pytest.mark.parametrize("hn,thresh,external_idxs", [(128, 0.99, True), (200, 0.99, False), (64, 0.999, False)])
+def test_literal_mode_bit_exact_with_oracle32(hn, thresh, external_idxs):
+    mask, planar, _, vnp = small_batch(b=2, first=510 + hn)
+    m, v = to_dev(mask, planar)
+    seed = 77
+    idxs_np = None
+    if external_idxs:  # SURVEY hard part 1: parity mode consumes the caller's idxs
+        rng = np.random.default_rng(5)
+        tns = [int(O.foreground(mask[i]).sum()) for i in range(2)]
+        idxs_np = np.stack([rng.integers(0, tns[i], (hn, 9, 2), dtype=np.int32) for i in range(2)])
+    out, dbg = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, seed=seed, literal=True,
+                                             idxs=None if idxs_np is None else torch.from_numpy(idxs_np).to(dev()),
+                                             return_debug=True)
+    ref, rdbg = O.ransac_voting_layer_v3(mask, vnp, hn, inlier_thresh=thresh, seed=seed, idxs=idxs_np,
+                                         dtype=np.float32, return_debug=True)
+    for bi, d in enumerate(rdbg):
+        hyp = dbg["hyp"][bi].cpu().numpy().transpose(1, 0, 2)  # -> [hn,vn,2]
+        assert hyp.tobytes() == d["hyp"].astype(np.float32).tobytes(), "hypotheses must be bit-exact"
+        np.testing.assert_array_equal(dbg["counts"][bi].cpu().numpy().T, d["counts"])  # exact inlier counts
+        np.testing.assert_array_equal(dbg["win"][bi, :, 0].cpu().numpy(), d["win_idx"])  # first-index tie-break
+        np.testing.assert_array_equal(dbg["win"][bi, :, 1].cpu().numpy(), d["win_cnt"])
+    assert np.abs(out.cpu().numpy() - ref).max() < 1e-4  # same inliers; float64 LSQ on both sides
+    # and the float64 oracle agrees to the north_star tolerance whenever it picks the same winners
+    o64, d64 = O.ransac_voting_layer_v3(mask, vnp, hn, inlier_thresh=thresh, seed=seed, idxs=idxs_np,
+                                        return_debug=True)
+    same = np.stack([d["win_idx"] for d in d64]) == dbg["win"][:, :, 0].cpu().numpy()
+    assert same.mean() > 0.8
+    assert np.abs(out.cpu().numpy() - o64)[same].max() < TOL_PX
+
+
+# ------------------------------------------------------------------------------------------------ fast mode
+def test_fast_mode_against_oracle64():
+    mask, planar, _, vnp = small_batch(b=3, first=530)
+    m, v = to_dev(mask, planar)
+    out, dbg = voting.ransac_voting_layer_v3(m, v, 256, inlier_thresh=0.99, seed=3, return_debug=True)
+    o64, d64 = O.ransac_voting_layer_v3(mask, vnp, 256, inlier_thresh=0.99, seed=3, return_debug=True)
+    cnt = dbg["counts"].cpu().numpy().transpose(0, 2, 1)
+    ref = np.stack([d["counts"] for d in d64])
+    diff = np.abs(cnt - ref)
+    assert diff.max() <= 3 and (diff > 0).mean() < 0.02  # only threshold-edge pixels may flip (SURVEY hard part 2)
+    same = np.stack([d["win_idx"] for d in d64]) == dbg["win"][:, :, 0].cpu().numpy()
+    assert same.mean() > 0.9
+    assert np.abs(out.cpu().numpy() - o64)[same].max() < TOL_PX
+
+
+def test_clean_field_recovers_keypoints_any_rng():
+    mask, planar, kpts, vnp = small_batch(b=4, first=540, noise=False)
+    m, v = to_dev(mask, planar)
+    a = voting.ransac_voting_layer_v3(m, v, 128, inlier_thresh=0.99, seed=1).cpu().numpy()
+    b = voting.ransac_voting_layer_v3(m, v, 128, inlier_thresh=0.99, seed=2).cpu().numpy()
+    o64 = O.ransac_voting_layer_v3(mask, vnp, 128, inlier_thresh=0.99, seed=9)
+    assert np.abs(a - o64).max() < TOL_PX and np.abs(b - o64).max() < TOL_PX
+    assert np.abs(a - kpts).max() < 5e-3  # float32 field quantisation only
+
+
+# ------------------------------------------------------------------------------------------------ boundary
+@pytest.mark.parametrize("dt", [torch.int64, torch.int32, torch.int16, torch.uint8, torch.bool, torch.float32,
+                                torch.float16])
+def test_mask_dtypes(dt):
+    mask, planar, _, _ = small_batch(b=1, first=550, h=96, w=128, radius=14)
+    m64, v = to_dev(mask, planar)
+    ref = voting.ransac_voting_layer_v3(m64, v, 64, inlier_thresh=0.99, seed=4)
+    out = voting.ransac_voting_layer_v3(m64.to(dt), v, 64, inlier_thresh=0.99, seed=4)
+    assert torch.equal(ref, out)
+
+
+def test_mask_byte_wraparound_and_strided_mask():
+    mask, planar, _, _ = small_batch(b=1, first=551, h=96, w=128, radius=14)
+    m, v = to_dev(mask, planar)
+    ref = voting.ransac_voting_layer_v3(m, v, 64, inlier_thresh=0.99, seed=4)
+    m2 = m.clone()
+    m2[m2 == 1] = 257  # .byte() -> 1 : still foreground
+    m2[0, 0, :5] = 256  # .byte() -> 0 : stays background (ransac_voting_gpu.py:527)
+    assert torch.equal(ref, voting.ransac_voting_layer_v3(m2, v, 64, inlier_thresh=0.99, seed=4))
+    wide = torch.zeros((1, 96, 256), dtype=torch.int64, device=dev())
+    wide[:, :, ::2] = m  # non-unit inner stride
+    assert torch.equal(ref, voting.ransac_voting_layer_v3(wide[:, :, ::2], v, 64, inlier_thresh=0.99, seed=4))
+
+
+def test_vertex_layouts_agree():
+    mask, planar, _, _ = small_batch(b=2, first=552, h=96, w=128, radius=14)
+    m, v = to_dev(mask, planar)
+    a = voting.ransac_voting_layer_v3(m, v, 64, inlier_thresh=0.99, seed=4)
+    b = voting.ransac_voting_layer_v3(m, v.contiguous(), 64, inlier_thresh=0.99, seed=4)
+    assert torch.equal(a, b)
+
+
+def test_min_num_and_empty_images():
+    mask, planar, _, vnp = small_batch(b=3, first=553, h=96, w=128, radius=14)
+    mask[1] = 0
+    mask[2] = 0
+    mask[2, 7, 7:11] = 1  # 4 px < min_num = 5
+    m, v = to_dev(mask, planar)
+    out, st = voting.ransac_voting_layer_v3(m, v, 64, inlier_thresh=0.99, seed=4, return_status=True)
+    out = out.cpu().numpy()
+    st = st.cpu().numpy()
+    assert (out[1:] == 0).all() and (st[1:] & voting.S_SKIPPED).all() and not (st[0] & voting.S_SKIPPED).any()
+    ref = O.ransac_voting_layer_v3(mask, vnp, 64, inlier_thresh=0.99, seed=4)
+    assert np.abs(out - ref).max() < TOL_PX
+
+
+def test_max_num_subsample_matches_oracle():
+    mask, planar, _, vnp = small_batch(b=2, first=554, h=120, w=160, radius=25)
+    m, v = to_dev(mask, planar)
+    out, dbg = voting.ransac_voting_layer_v3(m, v, 64, inlier_thresh=0.99, seed=11, max_num=300, literal=True,
+                                             return_debug=True)
+    ref, rdbg = O.ransac_voting_layer_v3(mask, vnp, 64, inlier_thresh=0.99, seed=11, max_num=300, dtype=np.float32,
+                                         return_debug=True)
+    for bi, d in enumerate(rdbg):
+        tn = int(dbg["tn"][bi])
+        assert tn == d["tn"] and 200 < tn < 400 < d["tn0"]  # Bernoulli(max_num/tn0), same counter RNG
+        pix = dbg["pix"][bi, :tn].cpu().numpy()
+        np.testing.assert_array_equal(pix, (d["coords"][:, 1] * 160 + d["coords"][:, 0]).astype(np.int64))
+        np.testing.assert_array_equal(dbg["win"][bi, :, 0].cpu().numpy(), d["win_idx"])
+    assert np.abs(out.cpu().numpy() - ref).max() < 1e-4
+
+
+@pytest.mark.parametrize("h,w,vn,hn", [(37, 53, 1, 100), (64, 64, 3, 33), (50, 200, 9, 520)])
+def test_odd_shapes(h, w, vn, hn):
+    mask, planar, _ = synth.make_batch(2, first_index=560, h=h, w=w, vn=vn, radius=9, noise=True,
+                                       background="normal")
+    vnp = synth.planar_to_vertex_view(planar)
+    m, v = to_dev(mask, planar)
+    out, dbg = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=0.99, seed=2, literal=True, return_debug=True)
+    ref, rdbg = O.ransac_voting_layer_v3(mask, vnp, hn, inlier_thresh=0.99, seed=2, dtype=np.float32,
+                                         return_debug=True)
+    for bi, d in enumerate(rdbg):
+        np.testing.assert_array_equal(dbg["counts"][bi].cpu().numpy().T, d["counts"])
+    assert np.abs(out.cpu().numpy() - ref).max() < 1e-4
+
+
+def test_no_inlier_and_singular_are_flagged_not_fatal():
+    # every direction is zero: no hypothesis, no inlier; the reference would raise inside torch.gesv (:511)
+    m = torch.zeros((1, 32, 32), dtype=torch.int64, device=dev())
+    m[0, 4:12, 4:12] = 1
+    v = torch.zeros((1, 32, 32, 2, 2), device=dev())
+    out, st = voting.ransac_voting_layer_v3(m, v, 64, inlier_thresh=0.99, seed=1, return_status=True)
+    assert (out == 0).all() and (st & voting.S_NO_INLIER).all() and (st & voting.S_SINGULAR).all()
+
+
+def test_determinism_stream_and_batch_equivariance():
+    mask, planar, _, _ = small_batch(b=4, first=570, h=96, w=128, radius=14)
+    m, v = to_dev(mask, planar)
+    tns = [int(O.foreground(mask[i]).sum()) for i in range(4)]
+    rng = np.random.default_rng(0)
+    idxs = torch.from_numpy(np.stack([rng.integers(0, t, (64, 9, 2), dtype=np.int32) for t in tns])).to(dev())
+    a = voting.ransac_voting_layer_v3(m, v, 64, inlier_thresh=0.99, idxs=idxs)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        b = voting.ransac_voting_layer_v3(m, v, 64, inlier_thresh=0.99, idxs=idxs)  # caller's stream is honoured
+    s.synchronize()
+    assert torch.equal(a, b)
+    perm = torch.tensor([2, 0, 3, 1], device=dev())
+    c = voting.ransac_voting_layer_v3(m[perm], v[perm], 64, inlier_thresh=0.99, idxs=idxs[perm])
+    assert torch.equal(a[perm], c)  # images are independent units (ransac_voting_gpu.py:525)
+
+
+# ------------------------------------------------------------------------------------------------ ops
+def test_ops_against_c_oracle():
+    mask, planar, _, vnp = small_batch(b=1, first=580, h=96, w=128, radius=14)
+    coords, direct = O.compact(O.foreground(mask[0]), vnp[0])
+    tn = coords.shape[0]
+    idxs = np.random.default_rng(1).integers(0, tn, (48, 9, 2), dtype=np.int32)
+    idxs[0, 0] = [3, 3]  # degenerate pair -> (0,0)
+    d, c, i = (torch.from_numpy(x).to(dev()) for x in (direct, coords, idxs))
+    hyp = voting.generate_hypothesis(d, c, i)
+    hyp_ref = cref.generate_hypothesis(direct, coords, idxs)
+    assert hyp.cpu().numpy().tobytes() == hyp_ref.tobytes()
+    inl = torch.zeros((48, 9, tn), dtype=torch.uint8, device=dev())
+    inl[5, 2, 7] = 9  # foreign value must survive: the op only ever stores ones (kernel.cu:124-125)
+    assert voting.voting_for_hypothesis(d, c, hyp, inl, 0.99) is None
+    ref = np.zeros((48, 9, tn), np.uint8)
+    ref[5, 2, 7] = 9
+    cref.voting_for_hypothesis(direct, coords, hyp_ref, ref, 0.99)
+    np.testing.assert_array_equal(inl.cpu().numpy(), ref)
+
+
+def test_ops_reject_bad_inputs_like_check_input():
+    d = torch.zeros((4, 2, 2), device=dev())
+    c = torch.zeros((4, 2), device=dev())
+    i = torch.zeros((3, 2, 2), dtype=torch.int32, device=dev())
+    with pytest.raises(RuntimeError, match="CUDA"):
+        voting.generate_hypothesis(d.cpu(), c, i)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        voting.generate_hypothesis(d.transpose(0, 1).contiguous().transpose(0, 1), c, i)
+    with pytest.raises(RuntimeError):
+        voting.ransac_voting_layer_v3(torch.zeros((1, 4, 4), dtype=torch.int64), torch.zeros((1, 4, 4, 2, 2)), 8)
+
+
+# ------------------------------------------------------------------------------------------------ full size
+def test_baseline_size_batch_against_c_oracle():
+    """BASELINE.json config 3 shapes (480x640, 9 kpts, 1024 hypotheses) on a batch of 4: literal mode must pick
+    the C oracle's winners exactly; the default fast mode must land within 1e-3 px wherever it agrees on the
+    winner, and that must be (almost) everywhere."""
+    mask, planar, kpts = synth.make_batch(4, first_index=0, radius=40, noise=True, background="normal")
+    vnp = synth.planar_to_vertex_view(planar)
+    m, v = to_dev(mask, planar)
+    ref, wi, wc = cref.vote_v3(O.foreground(mask), vnp, 1024, 0.99, seed=20240, return_winners=True)
+    lit, dl = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=20240, literal=True,
+                                            return_debug=True)
+    np.testing.assert_array_equal(dl["win"][:, :, 0].cpu().numpy(), wi)
+    np.testing.assert_array_equal(dl["win"][:, :, 1].cpu().numpy(), wc)
+    assert np.abs(lit.cpu().numpy() - ref).max() < 1e-4
+    fast, df = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=20240, return_debug=True)
+    same = df["win"][:, :, 0].cpu().numpy() == wi
+    assert same.mean() >= 0.9
+    assert np.abs(fast.cpu().numpy() - ref)[same].max() < TOL_PX
+    dcnt = (df["counts"] - dl["counts"]).abs()
+    assert int(dcnt.max()) <= 4
+
+
+def test_baseline_size_properties_batch32():
+    """size-independent properties at the full benchmark size (batch 32): clean fields vote back to their
+    generating key-points for any RNG seed, and the run is deterministic."""
+    mask, planar, kpts = synth.make_batch(32, first_index=0, radius=40, noise=False)
+    m, v = to_dev(mask, planar)
+    a = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=1)
+    b = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=1)
+    c = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=2)
+    assert torch.equal(a, b)
+    assert (a - c).abs().max().item() < TOL_PX
+    assert np.abs(a.cpu().numpy() - kpts).max() < 5e-3

@@ -1,0 +1,97 @@
+"""CPU-only checks of the C-ABI library and its host wrapper: it builds, loads, exports every symbol that
+include/pvnet_vote.h declares, validates arguments, and never falls back to a CPU path."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from pvnet_amd import build, voting
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build()
+    return voting.load_library()
+
+
+def test_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "pvnet_vote.h")).read()
+    names = set(re.findall(r"\b(pvnet_[a-z0-9_]+)\s*\(", hdr))
+    assert {"pvnet_vote_v3", "pvnet_vote_v3_profiled", "pvnet_generate_hypothesis", "pvnet_voting_for_hypothesis",
+            "pvnet_vote_workspace_bytes", "pvnet_vote_layout", "pvnet_vote_abi_version",
+            "pvnet_vote_build_info"} <= names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/pvnet_vote.h but not exported"
+    assert lib.pvnet_vote_abi_version() == 1
+    assert b"gfx950" in lib.pvnet_vote_build_info()
+
+
+def test_library_contains_gfx950_code_object():
+    blob = open(voting.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"score_kernel" in blob
+
+
+def test_layout_baseline_config(lib):
+    L = voting.vote_layout(32, 480, 640, 9, 1024, 30000)
+    assert (L.b, L.vn, L.hn, L.words) == (32, 9, 1024, 4800)
+    assert L.cap % 8 == 0 and 30000 < L.cap < 32000  # max_num + 8 sigma of the Bernoulli subsample
+    assert L.hn_pad == L.hgroups * 64 * L.hpl >= 1024 and L.max_chunks == -(-L.cap // L.chunk)
+    offs = [L.off_ctrl, L.off_bits, L.off_pix, L.off_rec, L.off_dir, L.off_hyp, L.off_partial, L.off_counts,
+            L.off_win, L.total_bytes]
+    assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
+    assert lib.pvnet_vote_workspace_bytes(32, 480, 640, 9, 1024, 30000) == L.total_bytes
+    full = voting.vote_layout(1, 480, 640, 9, 512, 10 ** 9)
+    assert full.cap == 480 * 640 + 8  # no subsampling possible -> every pixel may be foreground
+
+
+def test_argument_validation_without_a_gpu(lib):
+    assert lib.pvnet_vote_workspace_bytes(0, 480, 640, 9, 1024, 30000) == 0
+    L = voting.Layout()
+    assert lib.pvnet_vote_layout(1, 4, 4, 1, 0, 10, C.byref(L)) == -1  # PVNET_E_BADARG
+    ms = (C.c_int64 * 3)(16, 4, 1)
+    vs = (C.c_int64 * 5)(64, 16, 4, 2, 1)
+    rc = lib.pvnet_vote_v3(None, 3, ms, None, vs, 1, 4, 4, 2, 8, C.c_float(0.99), 5, 100, 0, None, 0, None, None,
+                           None, 0, None)
+    assert rc == -1
+    rc = lib.pvnet_generate_hypothesis(None, None, None, None, 1, 1, 1, None)
+    assert rc == -1
+
+
+def test_no_cpu_fallback():
+    with pytest.raises(RuntimeError, match="CUDA"):
+        voting.ransac_voting_layer_v3(torch.zeros((1, 8, 8), dtype=torch.int64), torch.zeros((1, 8, 8, 2, 2)), 16)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        voting.generate_hypothesis(torch.zeros(4, 1, 2), torch.zeros(4, 2), torch.zeros(2, 1, 2, dtype=torch.int32))
+    for f in os.listdir(os.path.join(ROOT, "pvnet_amd")):  # the product never imports the checker
+        if f.endswith(".py"):
+            src = open(os.path.join(ROOT, "pvnet_amd", f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(voting, "_lib", None)
+    monkeypatch.setattr(voting, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        voting.load_library()
+
+
+def test_reference_import_path_resolves_to_hip_layer():
+    import importlib
+    m = importlib.import_module("lib.ransac_voting_gpu_layer.ransac_voting_gpu")
+    assert m.ransac_voting_layer_v3 is voting.ransac_voting_layer_v3
+    import inspect
+    sig = inspect.signature(m.ransac_voting_layer_v3)
+    names = list(sig.parameters)[:8]
+    assert names == ["mask", "vertex", "round_hyp_num", "inlier_thresh", "confidence", "max_iter", "min_num",
+                     "max_num"]  # ransac_voting_gpu.py:514-515
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert (d["inlier_thresh"], d["confidence"], d["max_iter"], d["min_num"], d["max_num"]) == \
+           (0.999, 0.99, 20, 5, 30000)
+    ops = importlib.import_module("lib.ransac_voting_gpu_layer.ransac_voting")
+    for n in ("generate_hypothesis", "voting_for_hypothesis", "generate_hypothesis_vanishing_point",
+              "voting_for_hypothesis_vanishing_point"):  # ransac_voting.cpp:102-107
+        assert callable(getattr(ops, n))
