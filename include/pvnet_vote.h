@@ -42,7 +42,8 @@ extern "C" {
 
 /* flags */
 #define PVNET_F_LITERAL   1u       /* score with the reference's float32 operation order (sqrt + divide, one
-                                      rounding per op): bit-exact with oracle32.  Default: sqrt-free form. */
+                                      rounding per op): bit-exact with oracle32.  Default: the 7-op clamp-vote
+                                      form |d x u| < tan(acos(thresh)) * (d . u)  (pvnet_vote.hip: vote_fast) */
 #define PVNET_F_NO_REFINE 2u       /* skip ransac_voting_gpu.py:579-595, return the winning hypotheses */
 
 /* per-(image,key-point) status bits written to out_status */
@@ -60,18 +61,23 @@ typedef struct PvnetVoteLayout {
     int32_t chunk;          /* pixels per scoring work item                                                 */
     int32_t max_chunks;     /* ceil(cap / chunk)                                                            */
     int32_t hpl;            /* hypotheses per lane in the scoring kernel                                    */
-    int32_t hgroups;        /* hypothesis groups per key-point = ceil(hn / (64*hpl))                        */
+    int32_t hgroups;        /* hypothesis groups per key-point = ceil(hn / (64*hpl)) rounded up to wg_g     */
     int32_t hn_pad;         /* hgroups * 64 * hpl                                                           */
     size_t off_ctrl;        /* int32 [b][8]: tn0, tn, status, item_base, nchunks, -, -, -  ; then [8] global */
     size_t off_bits;        /* uint64 [b][words]           foreground (after subsampling) bit mask          */
     size_t off_pix;         /* int32  [b][cap]             linear pixel index y*w+x of compacted pixel t    */
-    size_t off_rec;         /* float4 [b][vn][cap]         scoring record (x, y, mx, my)                    */
+    size_t off_rec;         /* float4 [b][vn][cap]         scoring record (x, y, My, -Mx), M = 2^90 * direction     */
+    size_t off_tq;          /* float2 [b][vn][cap]         (Tx, Ty) = tan(acos(thresh)) * M                         */
     size_t off_dir;         /* float2 [b][vn][cap]         raw direction (ux, uy)                           */
     size_t off_hyp;         /* float2 [b][vn][hn_pad]      hypotheses                                       */
     size_t off_partial;     /* uint16 [b][vn][max_chunks][hn_pad]  per-chunk inlier counts                  */
     size_t off_counts;      /* int32  [b][vn][hn_pad]      inlier count of every hypothesis                 */
     size_t off_win;         /* int32  [b][vn][2]           (winner index, winner count)                     */
+    size_t off_seg;         /* int32  [b][nseg]            foreground count of every 4096-pixel segment     */
     size_t total_bytes;
+    int32_t nseg;           /* ceil(words / 64)                                                             */
+    int32_t wg_g, wg_s;     /* a scoring workgroup covers wg_g hypothesis groups x wg_s chunks (wg_g*wg_s=4) */
+    int32_t reserved_;
 } PvnetVoteLayout;
 
 /* Host-only: fills *out for a problem size.  max_num as passed to pvnet_vote_v3. */

@@ -44,8 +44,10 @@ __device__ constexpr float kF1e6 = 0x1.0c6f7ap-20f;
 constexpr int CTRL_STRIDE = 8;
 enum { C_TN0 = 0, C_TN = 1, C_STATUS = 2, C_ITEM_BASE = 3, C_NCHUNKS = 4 };
 
-constexpr int K1_WORDS_PER_WAVE = 8;   // 8 x 64 pixels per wave, 8 independent loads in flight per lane
-constexpr int K2_WORDS_PER_BLOCK = 64; // 4096 pixels per compaction block
+constexpr int SEG_WORDS = 64;          // a segment = 64 words = 4096 pixels: the unit of K1 / K1b / K2 workgroups
+constexpr int K1_WORDS_PER_WAVE = SEG_WORDS / 4;  // 16 independent loads in flight per lane
+constexpr int K2_WORDS_PER_BLOCK = SEG_WORDS;
+constexpr int K2_KG = 3;               // key-points per compaction block (grid.z = ceil(vn / 3))
 constexpr int PAD = 8;                 // scoring consumes records 8 at a time; tails are padded with sentinels
 
 struct VoteParams {
@@ -54,16 +56,19 @@ struct VoteParams {
     int mask_dtype, mask_linear;
     const float* vertex;
     int64_t vs0, vs1, vs2, vs3, vs4;
-    int b, h, w, vn, hn, npix, words, cap, chunk, max_chunks, hpl, hgroups, hn_pad;
-    float thresh;
+    int b, h, w, vn, hn, npix, words, cap, chunk, max_chunks, hpl, hgroups, hn_pad, wg_g, wg_s;
+    float thresh, tau;
     int min_num, max_num;
     uint64_t seed;
     const int32_t* idxs;
     uint32_t flags;
     int32_t* ctrl;
+    int32_t* seg;
+    int nseg;
     uint64_t* bits;
     int32_t* pix;
     float4* rec;
+    float2* tq;
     float2* dir;
     float2* hyp;
     uint16_t* partial;
@@ -105,13 +110,22 @@ __device__ __forceinline__ bool inlier_literal(float cx, float cy, float nx, flo
     return ang > thresh;
 }
 
-// sqrt-free form of the same predicate on a pre-scaled record: m = n / (|n| * thresh), thresh > 0
-//   cos > thresh  <=>  d.m > |d|  <=>  (d.m)|d.m| > |d|^2
-__device__ __forceinline__ bool inlier_fast(float cx, float cy, float mx, float my, float hx, float hy) {
+// Fast form of the same predicate on a pre-scaled record.  With tau = sqrt(1 - thresh^2) / thresh (0 < thresh < 1):
+//     cos(angle(d, u)) > thresh   <=>   |d x u| < tau * (d . u)          (scale-invariant in |u|: no normalisation)
+// The record carries M = 2^90 * u and T = tau * M, so   s = dy*Ty + (dx*Tx - |dx*My - dy*Mx|)   is 2^90 times the
+// margin: any non-zero float32 margin is then >= 1 in magnitude and the fma's CLAMP output modifier turns s into
+// exactly 1.0f (votes) or 0.0f (does not) -- the vote IS the arithmetic result: no compare, no carry, no scalar op.
+// 6 VALU ops (2 sub, mul, 3 fma) + 1 add to accumulate.  Angular resolution at the threshold is ~1e-7 rad in
+// float32, finer than the reference's own cos-based float32 test (~1e-6 rad: cos is flat where tan is steep).
+// Zero directions (|u| < 1e-6, kernel.cu:121) are stored as zero records and never vote; a hypothesis that sits
+// exactly on a pixel gives s = 0 and does not vote either, as in the reference.
+constexpr float kVoteScale = 0x1p90f;
+__device__ __forceinline__ float vote_fast(float cx, float cy, float My, float nMx, float Tx, float Ty, float hx,
+                                           float hy) {
     const float dx = hx - cx, dy = hy - cy;
-    const float dot = fmaf(dy, my, dx * mx);
-    const float l2 = fmaf(dy, dy, dx * dx);
-    return dot * fabsf(dot) > l2;
+    const float cr = fmaf(dy, nMx, dx * My);
+    const float e = fmaf(dx, Tx, -fabsf(cr));
+    return __builtin_amdgcn_fmed3f(fmaf(dy, Ty, e), 0.f, 1.f);  // folds into the fma's clamp bit
 }
 
 __device__ __forceinline__ int wave_reduce_add(int v) {
@@ -180,6 +194,7 @@ __global__ __launch_bounds__(256) void mask_bits_kernel(VoteParams P) {
     __syncthreads();
     if (threadIdx.x == 0) {
         const int t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        P.seg[bi * P.nseg + blockIdx.x] = t;  // foreground pixels of this 4096-pixel segment
         if (t) atomicAdd(&P.ctrl[bi * CTRL_STRIDE + C_TN0], t);
     }
 }
@@ -198,6 +213,7 @@ __global__ __launch_bounds__(256) void subsample_kernel(VoteParams P) {
     const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_SUB, (uint32_t)bi);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int word0 = (blockIdx.x * 4 + wave) * K1_WORDS_PER_WAVE;
+    int cnt = 0;
     for (int i = 0; i < K1_WORDS_PER_WAVE; ++i) {
         const int j = word0 + i;
         if (j >= P.words) break;
@@ -206,7 +222,12 @@ __global__ __launch_bounds__(256) void subsample_kernel(VoteParams P) {
         const bool keep = ((word >> lane) & 1ull) && pvnet_rng_at(key, (uint32_t)(j * 64 + lane)) < thr;
         const unsigned long long m = __ballot(keep);
         if (lane == 0) P.bits[(size_t)bi * P.words + j] = m;
+        cnt += __popcll(m);
     }
+    __shared__ int s_cnt[4];
+    if (lane == 0) s_cnt[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) P.seg[bi * P.nseg + blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -224,9 +245,12 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
     __shared__ uint64_t s_word[K2_WORDS_PER_BLOCK];
     __shared__ int s_total;
 
-    // pixels kept before this block = popcount of all earlier words (<= 38 KB of L2-resident bit mask)
+    // pixels kept before this block = sum of the earlier segments' counts (<= a few hundred ints)
+    const int32_t* sg = P.seg + bi * P.nseg;
+    const bool last = blockIdx.x == gridDim.x - 1;
+    if (!last && sg[blockIdx.x] == 0) return;  // block-uniform: most of the image is background
     int part = 0;
-    for (int j = threadIdx.x; j < w0; j += 256) part += __popcll(bw[j]);
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) part += sg[j];
     part = wave_reduce_add(part);
     if (lane == 0) s_red[wave] = part;
     if (wave == 0) {  // exclusive scan of this block's 64 word popcounts
@@ -245,10 +269,11 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
     __syncthreads();
     const int base = s_red[0] + s_red[1] + s_red[2] + s_red[3];
     const int usable = P.cap - PAD;
-    const float inv_t = 1.0f / P.thresh;
 
-    for (int i = 0; i < K2_WORDS_PER_BLOCK / 4; ++i) {
-        const int jj = wave * (K2_WORDS_PER_BLOCK / 4) + i;
+    // blockIdx.z selects a group of K2_KG key-points: 3x the blocks in flight and 2*K2_KG independent gathers
+    // per lane before the first use (the stage is latency-bound: ~13 active segments per 480x640 image)
+    const int k0 = blockIdx.z * K2_KG;
+    for (int jj = wave; jj < K2_WORDS_PER_BLOCK; jj += 4) {  // interleaved: a mask row alternates full/empty words
         const unsigned long long word = s_word[jj];
         if (word == 0) continue;  // wave-uniform: rows without foreground cost nothing
         const bool bit = (word >> lane) & 1ull;
@@ -256,43 +281,53 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
         if (bit && pos < usable) {
             const int p = (w0 + jj) * 64 + lane;
             const int y = p / P.w, x = p - y * P.w;
-            P.pix[(size_t)bi * P.cap + pos] = p;
+            if (k0 == 0) P.pix[(size_t)bi * P.cap + pos] = p;
             const float* v = P.vertex + (int64_t)bi * P.vs0 + (int64_t)y * P.vs1 + (int64_t)x * P.vs2;
-            for (int k = 0; k < P.vn; ++k) {
-                const float ux = v[(int64_t)k * P.vs3];
-                const float uy = v[(int64_t)k * P.vs3 + P.vs4];
-                const size_t o = ((size_t)bi * P.vn + k) * P.cap + pos;
-                P.dir[o] = make_float2(ux, uy);
-                float mx = ux, my = uy;
-                if (!LITERAL) {
-                    const float n1 = __builtin_sqrtf(fmaf(uy, uy, ux * ux));
-                    const float s = (n1 <= kF1e6) ? 0.f : inv_t / n1;  // zero direction never votes (:121)
-                    mx = ux * s;
-                    my = uy * s;
+            float ux[K2_KG], uy[K2_KG];
+#pragma unroll
+            for (int kk = 0; kk < K2_KG; ++kk) {
+                const int k = (k0 + kk < P.vn) ? k0 + kk : P.vn - 1;  // clamp: loads stay in bounds, unconditional
+                ux[kk] = v[(int64_t)k * P.vs3];
+                uy[kk] = v[(int64_t)k * P.vs3 + P.vs4];
+            }
+#pragma unroll
+            for (int kk = 0; kk < K2_KG; ++kk) {
+                if (k0 + kk >= P.vn) break;
+                const size_t o = ((size_t)bi * P.vn + k0 + kk) * P.cap + pos;
+                P.dir[o] = make_float2(ux[kk], uy[kk]);
+                if (LITERAL) {
+                    P.rec[o] = make_float4((float)x, (float)y, ux[kk], uy[kk]);
+                } else {
+                    const float n1 = __builtin_sqrtf(fmaf(uy[kk], uy[kk], ux[kk] * ux[kk]));
+                    const float sc = (n1 <= kF1e6) ? 0.f : kVoteScale;  // zero direction never votes (:121)
+                    const float Mx = ux[kk] * sc, My = uy[kk] * sc;
+                    P.rec[o] = make_float4((float)x, (float)y, My, -Mx);
+                    P.tq[o] = make_float2(P.tau * Mx, P.tau * My);
                 }
-                P.rec[o] = make_float4((float)x, (float)y, mx, my);
             }
         }
     }
-    if (blockIdx.x == gridDim.x - 1) {  // the block that owns the last word knows the total
+    if (last) {  // the block that owns the last segment knows the total
         const int total = base + s_total;
         const int tn = total < usable ? total : usable;
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0 && k0 == 0) {
             P.ctrl[bi * CTRL_STRIDE + C_TN] = tn;
             if (total > usable) P.ctrl[bi * CTRL_STRIDE + C_STATUS] = PVNET_S_OVERFLOW;
         }
         const int tpad = (tn + PAD - 1) / PAD * PAD;  // sentinel records: zero direction never votes
-        for (int i = threadIdx.x; i < (tpad - tn) * P.vn; i += 256) {
-            const int k = i / (tpad - tn), t = tn + i - k * (tpad - tn);
-            P.rec[((size_t)bi * P.vn + k) * P.cap + t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int kn = (k0 + K2_KG < P.vn ? k0 + K2_KG : P.vn) - k0;
+        for (int i = threadIdx.x; i < (tpad - tn) * kn; i += 256) {
+            const int kk = i / (tpad - tn), t = tn + i - kk * (tpad - tn);
+            P.rec[((size_t)bi * P.vn + k0 + kk) * P.cap + t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            P.tq[((size_t)bi * P.vn + k0 + kk) * P.cap + t] = make_float2(0.f, 0.f);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K2b: chunk counts + exclusive prefix of scoring work items   (gates of ransac_voting_gpu.py:531-534)
+// plan (runs in block (0,0) of the hypothesis launch): chunk counts + exclusive prefix of scoring work items
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void plan_kernel(VoteParams P) {
+__device__ __forceinline__ void plan_items(const VoteParams& P) {
     __shared__ int s_scan[256];
     __shared__ int s_running;
     if (threadIdx.x == 0) s_running = 0;
@@ -307,7 +342,7 @@ __global__ __launch_bounds__(256) void plan_kernel(VoteParams P) {
             const int nch = skip ? 0 : (tn + P.chunk - 1) / P.chunk;
             P.ctrl[i * CTRL_STRIDE + C_NCHUNKS] = nch;
             if (skip) P.ctrl[i * CTRL_STRIDE + C_STATUS] |= PVNET_S_SKIPPED;
-            n = nch * P.vn * P.hgroups;
+            n = ((nch + P.wg_s - 1) / P.wg_s) * P.vn * (P.hgroups / P.wg_g);  // workgroup items
         }
         s_scan[threadIdx.x] = n;
         __syncthreads();
@@ -331,11 +366,12 @@ __global__ __launch_bounds__(256) void plan_kernel(VoteParams P) {
 __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
     const int bi = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P.hn * P.vn) return;
+    const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
+    const bool live = P.ctrl[bi * CTRL_STRIDE + C_TN0] >= P.min_num && tn > 0;  // gates of :531-534
+    if (i < P.hn * P.vn) {
     const int h = i / P.vn, k = i - h * P.vn;
     float hx = 0.f, hy = 0.f;
-    if (P.ctrl[bi * CTRL_STRIDE + C_NCHUNKS] > 0) {
-        const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
+    if (live) {
         int t0, t1;
         if (P.idxs) {
             t0 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2];
@@ -355,57 +391,40 @@ __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
                       hx, hy);
     }
     P.hyp[((size_t)bi * P.vn + k) * P.hn_pad + h] = make_float2(hx, hy);
-}
-
-typedef __attribute__((address_space(4))) const float CFloat;
-
-constexpr int NB = 4;       // records per scalar-load batch (one s_load_dwordx16)
-constexpr int RB = NB * 4;  // floats per batch
-
-// 4 records = one s_load_dwordx16 into SGPRs (address is wave-uniform, constant address space)
-__device__ __forceinline__ void load_batch(const CFloat* r, int p, float (&q)[RB]) {
-#pragma unroll
-    for (int i = 0; i < RB; ++i) q[i] = r[p * 4 + i];
-}
-
-template <int HPL, bool LITERAL>
-__device__ __forceinline__ void score_batch(const float (&q)[RB], const float (&hx)[HPL], const float (&hy)[HPL],
-                                            int (&cnt)[HPL], float thresh) {
-#pragma unroll
-    for (int u = 0; u < NB; ++u) {
-        const float cx = q[u * 4], cy = q[u * 4 + 1], mx = q[u * 4 + 2], my = q[u * 4 + 3];
-#pragma unroll
-        for (int j = 0; j < HPL; ++j) {
-            if (LITERAL) {
-                cnt[j] += inlier_literal(cx, cy, mx, my, hx[j], hy[j], thresh) ? 1 : 0;
-            } else {
-                // 9 VALU ops per (hypothesis, pixel): 2 sub, mul+fma (d.m), mul+fma (|d|^2), mul, cmp, addc.
-                // The compare/accumulate pair is pinned in asm so that it stays v_cmp + v_addc (carry-in = vote).
-                const float dx = hx[j] - cx, dy = hy[j] - cy;
-                const float dot = fmaf(dy, my, dx * mx);
-                const float l2 = fmaf(dy, dy, dx * dx);
-                const float qq = dot * fabsf(dot);
-                asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc"
-                    : "+v"(cnt[j])
-                    : "v"(qq), "v"(l2)
-                    : "vcc");
-            }
-        }
     }
+    if (blockIdx.x == 0 && blockIdx.y == 0) plan_items(P);  // consumed by the next launches only
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // K4: inlier scoring                                           (kernel.cu:88-126 + ransac_voting_gpu.py:557-561)
+//
+// "Lane owns hypotheses": each lane keeps HPL hypotheses and their vote counters in VGPRs and walks the pixels of
+// a chunk; 7 VALU ops per (hypothesis, pixel) test in fast mode, all on VGPR operands.
+//
+// Measured on gfx950 (profiles/r01_ubench_valu.txt, r01_tune*.txt): a VALU op that takes an SGPR operand issues at
+// about half the rate of a VGPR-only one, so streaming the (wave-uniform) pixel records through the scalar cache
+// made a 7-op loop no faster than a 9-op one.  The records therefore go through LDS: a workgroup = 4 waves works on
+// ONE (image, key-point, chunk group); its 256 threads stage the chunk's records with one coalesced 16-byte and
+// one 8-byte load per thread, and every wave then reads them back as broadcast ds_read_b128 / ds_read_b64 (all
+// lanes the same address: conflict-free, LDS pipe, not VALU) -- the 4 waves cover G hypothesis groups x S chunks.
+// Work items are strided over a persistent grid; the per-chunk counts leave as coalesced uint16 rows.
 // ------------------------------------------------------------------------------------------------------------
+constexpr int NB = 4;  // pixels per inner-loop step (4 ds_read_b128 + 4 ds_read_b64 in flight)
+
 template <int HPL, bool LITERAL>
 __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int G = P.wg_g, S = P.wg_s;  // G * S == 4 waves
+    const int npx = S * P.chunk;
+    float4* s_rec = reinterpret_cast<float4*>(smem);
+    float2* s_tq = reinterpret_cast<float2*>(smem + (size_t)npx * sizeof(float4));
     const int lane = threadIdx.x & 63;
-    const int wave_gid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    const int nwaves = gridDim.x * 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int32_t* __restrict__ ctrl = P.ctrl;
     const int total = ctrl[P.b * CTRL_STRIDE];
+    const int HQ = P.hgroups / G;
 
-    for (int item = wave_gid; item < total; item += nwaves) {
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
         int lo = 0, hi = P.b - 1;  // image owning this item: last bi with item_base[bi] <= item
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
@@ -415,51 +434,67 @@ __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
         const int local = item - ctrl[bi * CTRL_STRIDE + C_ITEM_BASE];
         const int nch = ctrl[bi * CTRL_STRIDE + C_NCHUNKS];
         const int tn = ctrl[bi * CTRL_STRIDE + C_TN];
-        const int hg = local % P.hgroups;
-        const int t = local / P.hgroups;
-        const int c = t % nch;
-        const int k = t / nch;
-        const int p0 = c * P.chunk;
-        const int tpad = (tn + PAD - 1) / PAD * PAD;
-        const int p1 = (p0 + P.chunk < tpad) ? p0 + P.chunk : tpad;
+        const int nchg = (nch + S - 1) / S;
+        const int hq = local % HQ;
+        const int t = local / HQ;
+        const int cg = t % nchg;
+        const int k = t / nchg;
+        const size_t bk = (size_t)bi * P.vn + k;
+        const int tpad = (tn + PAD - 1) / PAD * PAD;  // records up to tpad exist (sentinels past tn)
 
-        const float2* __restrict__ hb = P.hyp + ((size_t)bi * P.vn + k) * P.hn_pad + (size_t)hg * 64 * HPL;
-        float hx[HPL], hy[HPL];
-        int cnt[HPL];
+        // ---- stage the chunk group's records in LDS
+        __syncthreads();  // the previous item's readers are done
+        for (int i = threadIdx.x; i < npx; i += 256) {
+            const int p = cg * npx + i;
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            float2 tq = make_float2(0.f, 0.f);
+            if (p < tpad) {
+                q = P.rec[bk * P.cap + p];
+                if (!LITERAL) tq = P.tq[bk * P.cap + p];
+            }
+            s_rec[i] = q;
+            if (!LITERAL) s_tq[i] = tq;
+        }
+        __syncthreads();
+
+        const int g = wave % G, sc = wave / G;
+        const int c = cg * S + sc;
+        if (c >= nch) continue;  // wave-uniform; barriers above are reached by every wave of the next trip
+        const int hg = hq * G + g;
+        const float2* __restrict__ hb = P.hyp + bk * P.hn_pad + (size_t)hg * 64 * HPL;
+        float hx[HPL], hy[HPL], cnt[HPL];
 #pragma unroll
         for (int j = 0; j < HPL; ++j) {
             const float2 hv = hb[j * 64 + lane];
             hx[j] = hv.x;
             hy[j] = hv.y;
-            cnt[j] = 0;
+            cnt[j] = 0.f;
         }
-        // Wave-uniform record stream.  The records were written by an earlier launch and are read-only here;
-        // viewing them through the constant address space makes every load an s_load_dwordx16 into SGPRs
-        // (scalar cache), which the VALU ops take as scalar operands -- no VGPRs, no VMEM issue slots.
-        // Scalar loads return out of order, so the only wait is lgkmcnt(0): the loop therefore (1) waits for
-        // the batch it is about to consume, (2) issues the next batch, (3) computes -- one batch is in flight
-        // for a whole compute phase (several hundred cycles).  The empty asm statements pin that order.
-        const CFloat* r = (const CFloat*)(P.rec + ((size_t)bi * P.vn + k) * P.cap);
-        float A[RB], B[RB];
-        load_batch(r, p0, A);
-        for (int p = p0; p < p1; p += 2 * NB) {  // p1 - p0 is a multiple of PAD = 2 * NB
-            if (!LITERAL) asm volatile("" ::"s"(A[0]), "s"(A[RB - 1]));
-            int pb = p + NB;
-            if (!LITERAL) asm volatile("" : "+s"(pb));
-            load_batch(r, pb, B);
-            if (!LITERAL) __builtin_amdgcn_sched_barrier(0);  // keep the load above the compute phase
-            score_batch<HPL, LITERAL>(A, hx, hy, cnt, P.thresh);
-            if (!LITERAL) asm volatile("" ::"s"(B[0]), "s"(B[RB - 1]));
-            int pa = (p + 2 * NB < p1) ? p + 2 * NB : p;  // last trip re-reads its own batch (discarded)
-            if (!LITERAL) asm volatile("" : "+s"(pa));
-            load_batch(r, pa, A);
-            if (!LITERAL) __builtin_amdgcn_sched_barrier(0);
-            score_batch<HPL, LITERAL>(B, hx, hy, cnt, P.thresh);
-        }
-        uint16_t* __restrict__ po =
-            P.partial + (((size_t)bi * P.vn + k) * P.max_chunks + c) * P.hn_pad + (size_t)hg * 64 * HPL;
+        const int n = (c * P.chunk + P.chunk <= tpad) ? P.chunk : tpad - c * P.chunk;  // multiple of PAD
+        const float4* sr = s_rec + sc * P.chunk;
+        const float2* st = s_tq + sc * P.chunk;
+        for (int i = 0; i < n; i += NB) {
+            float4 q[NB];
+            float2 tq[NB];
 #pragma unroll
-        for (int j = 0; j < HPL; ++j) po[j * 64 + lane] = (uint16_t)cnt[j];
+            for (int u = 0; u < NB; ++u) {
+                q[u] = sr[i + u];
+                if (!LITERAL) tq[u] = st[i + u];
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+#pragma unroll
+                for (int j = 0; j < HPL; ++j) {
+                    if (LITERAL)
+                        cnt[j] += inlier_literal(q[u].x, q[u].y, q[u].z, q[u].w, hx[j], hy[j], P.thresh) ? 1.f : 0.f;
+                    else
+                        cnt[j] += vote_fast(q[u].x, q[u].y, q[u].z, q[u].w, tq[u].x, tq[u].y, hx[j], hy[j]);
+                }
+            }
+        }
+        uint16_t* __restrict__ po = P.partial + (bk * P.max_chunks + c) * P.hn_pad + (size_t)hg * 64 * HPL;
+#pragma unroll
+        for (int j = 0; j < HPL; ++j) po[j * 64 + lane] = (uint16_t)(int)cnt[j];  // exact: counts < 2^24
     }
 }
 
@@ -492,10 +527,18 @@ __global__ __launch_bounds__(256) void select_refine_kernel(VoteParams P) {
     unsigned long long best = 0;
     for (int h = threadIdx.x; h < P.hn; h += 256) {
         const uint16_t* pp = P.partial + bk * P.max_chunks * P.hn_pad + h;
-        int s = 0;
-        for (int c = 0; c < nch; ++c) s += pp[(size_t)c * P.hn_pad];
-        P.counts[bk * P.hn_pad + h] = s;
-        const unsigned long long key = ((unsigned long long)(uint32_t)s << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)h);
+        int s0 = 0, s1 = 0, s2 = 0, s3 = 0;  // four independent chains: chunk loads overlap instead of serialising
+        int c = 0;
+        for (; c + 4 <= nch; c += 4) {
+            s0 += pp[(size_t)c * P.hn_pad];
+            s1 += pp[(size_t)(c + 1) * P.hn_pad];
+            s2 += pp[(size_t)(c + 2) * P.hn_pad];
+            s3 += pp[(size_t)(c + 3) * P.hn_pad];
+        }
+        for (; c < nch; ++c) s0 += pp[(size_t)c * P.hn_pad];
+        const int sum = (s0 + s1) + (s2 + s3);
+        P.counts[bk * P.hn_pad + h] = sum;
+        const unsigned long long key = ((unsigned long long)(uint32_t)sum << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)h);
         best = key > best ? key : best;
     }
     best = wave_reduce_max(best);
@@ -530,21 +573,26 @@ __global__ __launch_bounds__(256) void select_refine_kernel(VoteParams P) {
     const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
     double a = 0, bb = 0, d = 0, r0 = 0, r1 = 0;
     int n = 0;
+#pragma unroll 4
     for (int t = threadIdx.x; t < tn; t += 256) {
         const float4 q = P.rec[bk * P.cap + t];
         const float2 u = P.dir[bk * P.cap + t];
-        const bool in = LITERAL ? inlier_literal(q.x, q.y, u.x, u.y, wx, wy, P.thresh)
-                                : inlier_fast(q.x, q.y, q.z, q.w, wx, wy);
-        if (in) {
-            const double nx = (double)u.y, ny = -(double)u.x;  // normal = (dy, -dx) (:580-581)
-            const double bv = nx * ((double)q.x - (double)wx) + ny * ((double)q.y - (double)wy);
-            a += nx * nx;
-            bb += nx * ny;
-            d += ny * ny;
-            r0 += nx * bv;
-            r1 += ny * bv;
-            ++n;
+        bool in;
+        if (LITERAL) {
+            in = inlier_literal(q.x, q.y, u.x, u.y, wx, wy, P.thresh);
+        } else {
+            const float2 tq = P.tq[bk * P.cap + t];
+            in = vote_fast(q.x, q.y, q.z, q.w, tq.x, tq.y, wx, wy) > 0.5f;  // the very predicate that scored
         }
+        const double wgt = in ? 1.0 : 0.0;  // predicated, not branched
+        const double nx = (double)u.y * wgt, ny = -(double)u.x * wgt;  // normal = (dy, -dx) (:580-581)
+        const double bv = nx * ((double)q.x - (double)wx) + ny * ((double)q.y - (double)wy);
+        a += nx * nx;
+        bb += nx * ny;
+        d += ny * ny;
+        r0 += nx * bv;
+        r1 += ny * bv;
+        n += in ? 1 : 0;
     }
     a = wave_reduce_add(a);
     bb = wave_reduce_add(bb);
@@ -653,11 +701,12 @@ int num_cus() {
 
 template <bool LITERAL>
 int launch_score(const VoteParams& P, dim3 grid, hipStream_t s) {
+    const size_t lds = (size_t)P.wg_s * P.chunk * (sizeof(float4) + sizeof(float2));
     switch (P.hpl) {
-        case 1: hipLaunchKernelGGL((score_kernel<1, LITERAL>), grid, dim3(256), 0, s, P); break;
-        case 2: hipLaunchKernelGGL((score_kernel<2, LITERAL>), grid, dim3(256), 0, s, P); break;
-        case 4: hipLaunchKernelGGL((score_kernel<4, LITERAL>), grid, dim3(256), 0, s, P); break;
-        case 8: hipLaunchKernelGGL((score_kernel<8, LITERAL>), grid, dim3(256), 0, s, P); break;
+        case 1: hipLaunchKernelGGL((score_kernel<1, LITERAL>), grid, dim3(256), lds, s, P); break;
+        case 2: hipLaunchKernelGGL((score_kernel<2, LITERAL>), grid, dim3(256), lds, s, P); break;
+        case 4: hipLaunchKernelGGL((score_kernel<4, LITERAL>), grid, dim3(256), lds, s, P); break;
+        case 8: hipLaunchKernelGGL((score_kernel<8, LITERAL>), grid, dim3(256), lds, s, P); break;
         default: return PVNET_E_UNSUPPORTED;
     }
     return 0;
@@ -669,8 +718,7 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
     PV_HIP(hipMemsetAsync(P.ctrl, 0, sizeof(int32_t) * CTRL_STRIDE * (size_t)(P.b + 1), s));
     PV_HIP(mark(0));
     {   // K1
-        const int wpb = 4 * K1_WORDS_PER_WAVE;
-        dim3 grid((P.words + wpb - 1) / wpb, P.b);
+        dim3 grid(P.nseg, P.b);
         switch (P.mask_dtype) {
             case PVNET_MASK_U8: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_U8>, grid, dim3(256), 0, s, P); break;
             case PVNET_MASK_I16: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I16>, grid, dim3(256), 0, s, P); break;
@@ -688,15 +736,13 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
         PV_HIP(mark(2));
     }
     {   // K2
-        dim3 grid((P.words + K2_WORDS_PER_BLOCK - 1) / K2_WORDS_PER_BLOCK, P.b);
+        dim3 grid(P.nseg, P.b, (P.vn + K2_KG - 1) / K2_KG);
         if (literal) hipLaunchKernelGGL(compact_kernel<true>, grid, dim3(256), 0, s, P);
         else hipLaunchKernelGGL(compact_kernel<false>, grid, dim3(256), 0, s, P);
         PV_LAUNCH_CHECK();
         PV_HIP(mark(3));
     }
-    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(256), 0, s, P);
-    PV_LAUNCH_CHECK();
-    PV_HIP(mark(4));
+    PV_HIP(mark(4));  // (the work-item plan is computed by block (0,0) of the hypothesis launch)
     {   // K3
         dim3 grid((P.hn * P.vn + 255) / 256, P.b);
         hipLaunchKernelGGL(hypothesis_kernel, grid, dim3(256), 0, s, P);
@@ -704,10 +750,11 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
         PV_HIP(mark(5));
     }
     {   // K4: persistent grid, work items strided over its waves
-        const long long max_items = (long long)P.b * P.vn * P.hgroups * P.max_chunks;
-        const int wgs_per_cu = env_int("PVNET_SCORE_WGS_PER_CU", 4);
+        const long long max_items =
+            (long long)P.b * P.vn * (P.hgroups / P.wg_g) * ((P.max_chunks + P.wg_s - 1) / P.wg_s);
+        const int wgs_per_cu = env_int("PVNET_SCORE_WGS_PER_CU", 8);
         long long wgs = (long long)num_cus() * wgs_per_cu;
-        if (wgs > (max_items + 3) / 4) wgs = (max_items + 3) / 4;
+        if (wgs > max_items) wgs = max_items;
         if (wgs < 1) wgs = 1;
         int rc = literal ? launch_score<true>(P, dim3((unsigned)wgs), s) : launch_score<false>(P, dim3((unsigned)wgs), s);
         if (rc) return rc;
@@ -736,7 +783,7 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     if (ws_bytes < L.total_bytes) return PVNET_E_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(ws) & 255u) != 0) return PVNET_E_BADARG;
     // the sqrt-free predicate folds 1/thresh into the records: needs thresh > 0; otherwise score literally
-    if (!(thresh > 0.f)) flags |= PVNET_F_LITERAL;
+    if (!(thresh > 0.f && thresh < 1.f)) flags |= PVNET_F_LITERAL;
     char* base = static_cast<char*>(ws);
     P.mask = mask; P.ms0 = ms[0]; P.ms1 = ms[1]; P.ms2 = ms[2];
     P.mask_dtype = mask_dtype;
@@ -744,12 +791,17 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     P.vertex = vertex; P.vs0 = vs[0]; P.vs1 = vs[1]; P.vs2 = vs[2]; P.vs3 = vs[3]; P.vs4 = vs[4];
     P.b = b; P.h = h; P.w = w; P.vn = vn; P.hn = hn; P.npix = h * w;
     P.words = L.words; P.cap = L.cap; P.chunk = L.chunk; P.max_chunks = L.max_chunks;
-    P.hpl = L.hpl; P.hgroups = L.hgroups; P.hn_pad = L.hn_pad;
-    P.thresh = thresh; P.min_num = min_num; P.max_num = max_num; P.seed = seed; P.idxs = idxs; P.flags = flags;
+    P.hpl = L.hpl; P.hgroups = L.hgroups; P.hn_pad = L.hn_pad; P.wg_g = L.wg_g; P.wg_s = L.wg_s;
+    P.thresh = thresh;
+    P.tau = (thresh > 0.f && thresh < 1.f) ? (float)(sqrt(1.0 - (double)thresh * thresh) / (double)thresh) : 0.f;
+    P.min_num = min_num; P.max_num = max_num; P.seed = seed; P.idxs = idxs; P.flags = flags;
     P.ctrl = reinterpret_cast<int32_t*>(base + L.off_ctrl);
+    P.seg = reinterpret_cast<int32_t*>(base + L.off_seg);
+    P.nseg = L.nseg;
     P.bits = reinterpret_cast<uint64_t*>(base + L.off_bits);
     P.pix = reinterpret_cast<int32_t*>(base + L.off_pix);
     P.rec = reinterpret_cast<float4*>(base + L.off_rec);
+    P.tq = reinterpret_cast<float2*>(base + L.off_tq);
     P.dir = reinterpret_cast<float2*>(base + L.off_dir);
     P.hyp = reinterpret_cast<float2*>(base + L.off_hyp);
     P.partial = reinterpret_cast<uint16_t*>(base + L.off_partial);
@@ -782,11 +834,14 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     int hpl = hn >= 512 ? 4 : (hn >= 128 ? 2 : 1);
     hpl = env_int("PVNET_SCORE_HPL", hpl);
     if (hpl != 1 && hpl != 2 && hpl != 4 && hpl != 8) return PVNET_E_UNSUPPORTED;
-    const int hgroups = (hn + 64 * hpl - 1) / (64 * hpl);
+    int hgroups = (hn + 64 * hpl - 1) / (64 * hpl);
+    // a scoring workgroup (4 waves) covers wg_g hypothesis groups x wg_s chunks of one (image, key-point)
+    const int wg_g = hgroups >= 3 ? 4 : hgroups;
+    hgroups = (hgroups + wg_g - 1) / wg_g * wg_g;
     const long long units = (long long)b * vn * hgroups;
     int chunk = units >= 512 ? 256 : (units >= 128 ? 128 : 64);
     chunk = env_int("PVNET_SCORE_CHUNK", chunk);
-    if (chunk < PAD || chunk % PAD != 0 || chunk > 65528) return PVNET_E_UNSUPPORTED;
+    if (chunk < PAD || chunk % PAD != 0 || chunk > 1024) return PVNET_E_UNSUPPORTED;  // LDS: 4 * 1024 * 24 B
     L->b = b; L->h = h; L->w = w; L->vn = vn; L->hn = hn;
     L->cap = (int)cap;
     L->words = (int)((npix + 63) / 64);
@@ -795,12 +850,17 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     L->hpl = hpl;
     L->hgroups = hgroups;
     L->hn_pad = hgroups * 64 * hpl;
+    L->wg_g = wg_g;
+    L->wg_s = 4 / wg_g;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L->nseg = (L->words + SEG_WORDS - 1) / SEG_WORDS;
     L->off_ctrl = take(sizeof(int32_t) * CTRL_STRIDE * (size_t)(b + 1));
+    L->off_seg = take(sizeof(int32_t) * (size_t)b * L->nseg);
     L->off_bits = take(sizeof(uint64_t) * (size_t)b * L->words);
     L->off_pix = take(sizeof(int32_t) * (size_t)b * cap);
     L->off_rec = take(sizeof(float) * 4 * (size_t)b * vn * cap);
+    L->off_tq = take(sizeof(float) * 2 * (size_t)b * vn * cap);
     L->off_dir = take(sizeof(float) * 2 * (size_t)b * vn * cap);
     L->off_hyp = take(sizeof(float) * 2 * (size_t)b * vn * L->hn_pad);
     L->off_partial = take(sizeof(uint16_t) * (size_t)b * vn * L->max_chunks * L->hn_pad);

@@ -34,8 +34,9 @@ class Layout(C.Structure):
     """ctypes image of ``PvnetVoteLayout`` (include/pvnet_vote.h)."""
     _fields_ = [(n, C.c_int32) for n in ("b", "h", "w", "vn", "hn", "cap", "words", "chunk", "max_chunks", "hpl",
                                           "hgroups", "hn_pad")] + \
-               [(n, C.c_size_t) for n in ("off_ctrl", "off_bits", "off_pix", "off_rec", "off_dir", "off_hyp",
-                                          "off_partial", "off_counts", "off_win", "total_bytes")]
+               [(n, C.c_size_t) for n in ("off_ctrl", "off_bits", "off_pix", "off_rec", "off_tq", "off_dir", "off_hyp",
+                                          "off_partial", "off_counts", "off_win", "off_seg", "total_bytes")] + \
+               [("nseg", C.c_int32), ("wg_g", C.c_int32), ("wg_s", C.c_int32), ("reserved_", C.c_int32)]
 
 
 _lib = None
