@@ -92,6 +92,8 @@ size_t pvnet_vote_workspace_bytes(int b, int h, int w, int vn, int hn, int max_n
  *   hn              round_hyp_num
  *   inlier_thresh, min_num, max_num   as the reference's keyword arguments
  *   seed            counter-RNG seed (pixel pairs when idxs == NULL; Bernoulli subsample when tn0 > max_num)
+ *   image_base      global index of image 0 of this call: the RNG stream of image i is image_base + i, so a batch
+ *                   sharded over GPUs draws exactly what the unsharded batch would (0 for a whole batch)
  *   idxs            NULL, or int32 [b,hn,vn,2] pixel-pair indices into each image's compacted list
  *   out_kpts        [b,vn,2] float32
  *   out_status      NULL or int32 [b,vn] PVNET_S_* bits
@@ -101,7 +103,7 @@ int pvnet_vote_v3(const void* mask, int mask_dtype, const int64_t mask_strides[3
                   const float* vertex, const int64_t vertex_strides[5],
                   int b, int h, int w, int vn, int hn,
                   float inlier_thresh, int min_num, int max_num,
-                  uint64_t seed, const int32_t* idxs, uint32_t flags,
+                  uint64_t seed, int image_base, const int32_t* idxs, uint32_t flags,
                   float* out_kpts, int32_t* out_status,
                   void* workspace, size_t workspace_bytes, void* stream);
 
@@ -119,7 +121,7 @@ int pvnet_vote_v3_profiled(const void* mask, int mask_dtype, const int64_t mask_
                            const float* vertex, const int64_t vertex_strides[5],
                            int b, int h, int w, int vn, int hn,
                            float inlier_thresh, int min_num, int max_num,
-                           uint64_t seed, const int32_t* idxs, uint32_t flags,
+                           uint64_t seed, int image_base, const int32_t* idxs, uint32_t flags,
                            float* out_kpts, int32_t* out_status,
                            void* workspace, size_t workspace_bytes, void* stream, float* stage_ms);
 

@@ -214,7 +214,7 @@ def refine(direct, coords, win_pts, thresh, dtype=np.float64, lsq_dtype=np.float
 # Driver
 # ----------------------------------------------------------------------------------------------------
 def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99, max_iter=20,
-                           min_num=5, max_num=30000, *, idxs=None, keep=None, seed=0, dtype=np.float64,
+                           min_num=5, max_num=30000, *, idxs=None, keep=None, seed=0, image_offset=0, dtype=np.float64,
                            lsq_dtype=np.float64, emulate_rounds=False, return_debug=False):
     """ransac_voting_gpu.py:514-598 on numpy arrays.
 
@@ -243,7 +243,7 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
             continue
         if tn0 > max_num:  # :537-540
             kp = (np.asarray(keep[bi], bool).reshape(h, w) if keep is not None
-                  else subsample_keep(seed, bi, h * w, max_num, tn0).reshape(h, w))
+                  else subsample_keep(seed, image_offset + bi, h * w, max_num, tn0).reshape(h, w))
             fg = fg & kp
         coords, direct = compact(fg, vertex[bi])  # :542-546
         tn = coords.shape[0]
@@ -253,7 +253,7 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
             dbg.append(info)
             continue
         if idxs is None:
-            ix = draw_idxs(seed, bi, hn, vn, tn)  # :547
+            ix = draw_idxs(seed, image_offset + bi, hn, vn, tn)  # :547
         else:
             ix = np.asarray(idxs)
             ix = ix[bi] if ix.ndim == 4 else ix

@@ -60,6 +60,7 @@ struct VoteParams {
     float thresh, tau;
     int min_num, max_num;
     uint64_t seed;
+    int image_base;
     const int32_t* idxs;
     uint32_t flags;
     int32_t* ctrl;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void subsample_kernel(VoteParams P) {
     const double t = ceil((double)p * 4294967296.0);
     if (t >= 4294967296.0) return;
     const uint32_t thr = (uint32_t)t;
-    const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_SUB, (uint32_t)bi);
+    const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_SUB, (uint32_t)(P.image_base + bi));
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int word0 = (blockIdx.x * 4 + wave) * K1_WORDS_PER_WAVE;
     int cnt = 0;
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
             t0 = t0 < 0 ? 0 : (t0 >= tn ? tn - 1 : t0);  // memory safety only; valid idxs are untouched
             t1 = t1 < 0 ? 0 : (t1 >= tn ? tn - 1 : t1);
         } else {
-            const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_HYP, (uint32_t)bi);
+            const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_HYP, (uint32_t)(P.image_base + bi));
             t0 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u), (uint32_t)tn);
             t1 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u + 1u), (uint32_t)tn);
         }
@@ -773,8 +774,8 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
 
 int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* ms, const float* vertex,
                 const int64_t* vs, int b, int h, int w, int vn, int hn, float thresh, int min_num, int max_num,
-                uint64_t seed, const int32_t* idxs, uint32_t flags, float* out, int32_t* status, void* ws,
-                size_t ws_bytes) {
+                uint64_t seed, int image_base, const int32_t* idxs, uint32_t flags, float* out, int32_t* status,
+                void* ws, size_t ws_bytes) {
     if (!mask || !vertex || !ms || !vs || !out || !ws) return PVNET_E_BADARG;
     if (mask_dtype < PVNET_MASK_U8 || mask_dtype > PVNET_MASK_F32) return PVNET_E_BADARG;
     PvnetVoteLayout L;
@@ -794,7 +795,7 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     P.hpl = L.hpl; P.hgroups = L.hgroups; P.hn_pad = L.hn_pad; P.wg_g = L.wg_g; P.wg_s = L.wg_s;
     P.thresh = thresh;
     P.tau = (thresh > 0.f && thresh < 1.f) ? (float)(sqrt(1.0 - (double)thresh * thresh) / (double)thresh) : 0.f;
-    P.min_num = min_num; P.max_num = max_num; P.seed = seed; P.idxs = idxs; P.flags = flags;
+    P.min_num = min_num; P.max_num = max_num; P.seed = seed; P.image_base = image_base; P.idxs = idxs; P.flags = flags;
     P.ctrl = reinterpret_cast<int32_t*>(base + L.off_ctrl);
     P.seg = reinterpret_cast<int32_t*>(base + L.off_seg);
     P.nseg = L.nseg;
@@ -877,24 +878,26 @@ size_t pvnet_vote_workspace_bytes(int b, int h, int w, int vn, int hn, int max_n
 
 int pvnet_vote_v3(const void* mask, int mask_dtype, const int64_t mask_strides[3], const float* vertex,
                   const int64_t vertex_strides[5], int b, int h, int w, int vn, int hn, float inlier_thresh,
-                  int min_num, int max_num, uint64_t seed, const int32_t* idxs, uint32_t flags, float* out_kpts,
-                  int32_t* out_status, void* workspace, size_t workspace_bytes, void* stream) {
+                  int min_num, int max_num, uint64_t seed, int image_base, const int32_t* idxs, uint32_t flags,
+                  float* out_kpts, int32_t* out_status, void* workspace, size_t workspace_bytes, void* stream) {
     VoteParams P;
     int rc = fill_params(P, mask, mask_dtype, mask_strides, vertex, vertex_strides, b, h, w, vn, hn, inlier_thresh,
-                         min_num, max_num, seed, idxs, flags, out_kpts, out_status, workspace, workspace_bytes);
+                         min_num, max_num, seed, image_base, idxs, flags, out_kpts, out_status, workspace,
+                         workspace_bytes);
     if (rc) return rc;
     return launch_all(P, static_cast<hipStream_t>(stream), nullptr);
 }
 
 int pvnet_vote_v3_profiled(const void* mask, int mask_dtype, const int64_t mask_strides[3], const float* vertex,
                            const int64_t vertex_strides[5], int b, int h, int w, int vn, int hn,
-                           float inlier_thresh, int min_num, int max_num, uint64_t seed, const int32_t* idxs,
-                           uint32_t flags, float* out_kpts, int32_t* out_status, void* workspace,
-                           size_t workspace_bytes, void* stream, float* stage_ms) {
+                           float inlier_thresh, int min_num, int max_num, uint64_t seed, int image_base,
+                           const int32_t* idxs, uint32_t flags, float* out_kpts, int32_t* out_status,
+                           void* workspace, size_t workspace_bytes, void* stream, float* stage_ms) {
     if (!stage_ms) return PVNET_E_BADARG;
     VoteParams P;
     int rc = fill_params(P, mask, mask_dtype, mask_strides, vertex, vertex_strides, b, h, w, vn, hn, inlier_thresh,
-                         min_num, max_num, seed, idxs, flags, out_kpts, out_status, workspace, workspace_bytes);
+                         min_num, max_num, seed, image_base, idxs, flags, out_kpts, out_status, workspace,
+                         workspace_bytes);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipEvent_t ev[PVNET_NUM_STAGES + 1];

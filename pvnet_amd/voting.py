@@ -59,7 +59,7 @@ def load_library() -> C.CDLL:
     lib.pvnet_vote_workspace_bytes.restype = C.c_size_t
     lib.pvnet_vote_workspace_bytes.argtypes = [C.c_int] * 6
     v3_args = [C.c_void_p, C.c_int, i64p, f32p, i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
-               C.c_int, C.c_int, C.c_uint64, i32p, C.c_uint32, f32p, i32p, C.c_void_p, C.c_size_t, C.c_void_p]
+               C.c_int, C.c_int, C.c_uint64, C.c_int, i32p, C.c_uint32, f32p, i32p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.pvnet_vote_v3.restype = C.c_int
     lib.pvnet_vote_v3.argtypes = v3_args
     lib.pvnet_vote_v3_profiled.restype = C.c_int
@@ -149,7 +149,7 @@ def _debug_views(ws: torch.Tensor, L: Layout):
 
 def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99, max_iter=20,
                            min_num=5, max_num=30000, *, idxs: Optional[torch.Tensor] = None,
-                           seed: Optional[int] = None, literal: bool = False, refine: bool = True,
+                           seed: Optional[int] = None, image_offset: int = 0, literal: bool = False, refine: bool = True,
                            return_status: bool = False, return_debug: bool = False, stage_times: bool = False):
     """Drop-in for the reference's ``ransac_voting_layer_v3`` (ransac_voting_gpu.py:514-598).
 
@@ -166,6 +166,8 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
       idxs    int tensor [b,hn,vn,2] (or [hn,vn,2]): pixel-pair indices into each image's raster-ordered
               foreground list, replacing the internal counter RNG (parity runs against the oracle)
       seed    RNG seed (default: drawn from torch's CPU generator, so ``torch.manual_seed`` makes runs repeatable)
+      image_offset  global index of this call's first image (RNG stream = image_offset + i): lets a batch sharded
+              over GPUs reproduce the unsharded draw exactly
       literal score with the reference's float32 operation order (bit-exact with the float32 oracle, slower)
       refine  False skips the least-squares refinement (:579-595) and returns the winning hypotheses
       return_status / return_debug / stage_times: also return the per-(image,kp) status bits / typed views of
@@ -185,7 +187,7 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
         stream = torch.cuda.current_stream(dev).cuda_stream
         args = [C.c_void_p(mask.data_ptr()), _MASK_CODES[mask.dtype], _strides(mask, 3),
                 C.c_void_p(vertex.data_ptr()), _strides(vertex, 5), b, h, w, vn, hn, C.c_float(inlier_thresh),
-                int(min_num), max_num, C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF),
+                int(min_num), max_num, C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), int(image_offset),
                 C.c_void_p(idxs.data_ptr()) if idxs is not None else None, flags, C.c_void_p(out.data_ptr()),
                 C.c_void_p(status.data_ptr()) if status is not None else None, C.c_void_p(ws.data_ptr()),
                 C.c_size_t(L.total_bytes), C.c_void_p(stream)]

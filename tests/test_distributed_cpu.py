@@ -1,0 +1,69 @@
+"""world_size-2 gloo tests of the sharding / gather logic (pvnet_amd/distributed.py).  No GPU here, so the voter
+is injected: the numpy oracle plays the voter *as the checker's stand-in* -- this tests the N>1 plumbing
+(shard ownership, global RNG streams, the single all-gather, ragged tails), not the HIP kernels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ransac_voting_oracle as O
+from pvnet_amd import distributed as D
+from pvnet_amd import synth
+
+
+def test_shard_ranges_partition_the_batch():
+    for total in (1, 7, 32, 33, 256):
+        for world in (1, 2, 3, 8):
+            r = [D.shard_range(total, world, k) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == total
+            assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+            sizes = [e - s for s, e in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _oracle_voter(mask, vertex, hn, *a, seed=0, image_offset=0, **kw):
+    out = O.ransac_voting_layer_v3(mask.numpy(), vertex.numpy(), hn, *a, seed=seed, image_offset=image_offset, **kw)
+    return torch.from_numpy(out)
+
+
+def _worker(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mask, planar, _ = synth.make_batch(total, first_index=900, h=64, w=80, radius=9, noise=True)
+        vertex = synth.planar_to_vertex_view(planar)
+        s, e = D.shard_range(total, world, rank)
+        full = D.sharded_ransac_voting_layer_v3(torch.from_numpy(mask[s:e]), torch.from_numpy(vertex[s:e].copy()), 32,
+                                                0.99, total=total, voter=_oracle_voter, seed=5)
+        q.put((rank, full.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("total", [4, 5])  # even split -> all_gather_into_tensor; ragged tail -> padded gather
+def test_two_ranks_reproduce_the_unsharded_batch(total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mask, planar, _ = synth.make_batch(total, first_index=900, h=64, w=80, radius=9, noise=True)
+    ref = O.ransac_voting_layer_v3(mask, synth.planar_to_vertex_view(planar), 32, 0.99, seed=5)
+    for r in range(2):
+        assert res[r].shape == (total, 9, 2)
+        np.testing.assert_array_equal(res[r], ref)  # same global RNG streams, same order, on every rank

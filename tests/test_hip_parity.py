@@ -295,3 +295,15 @@ def test_baseline_size_properties_batch32():
     assert torch.equal(a, b)
     assert (a - c).abs().max().item() < TOL_PX
     assert np.abs(a.cpu().numpy() - kpts).max() < 5e-3
+
+
+def test_sharded_calls_reproduce_the_whole_batch():
+    """image_offset makes image i of a shard draw the RNG stream of its GLOBAL index (multi-GPU)."""
+    mask, planar, _, _ = small_batch(b=4, first=590, h=96, w=128, radius=14)
+    m, v = to_dev(mask, planar)
+    whole = voting.ransac_voting_layer_v3(m, v, 64, inlier_thresh=0.99, seed=8)
+    lo = voting.ransac_voting_layer_v3(m[:2], v[:2], 64, inlier_thresh=0.99, seed=8, image_offset=0)
+    hi = voting.ransac_voting_layer_v3(m[2:], v[2:], 64, inlier_thresh=0.99, seed=8, image_offset=2)
+    assert torch.equal(whole, torch.cat([lo, hi]))
+    wrong = voting.ransac_voting_layer_v3(m[2:], v[2:], 64, inlier_thresh=0.99, seed=8, image_offset=0)
+    assert not torch.equal(whole[2:], wrong)

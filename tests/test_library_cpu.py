@@ -54,7 +54,7 @@ def test_argument_validation_without_a_gpu(lib):
     assert lib.pvnet_vote_layout(1, 4, 4, 1, 0, 10, C.byref(L)) == -1  # PVNET_E_BADARG
     ms = (C.c_int64 * 3)(16, 4, 1)
     vs = (C.c_int64 * 5)(64, 16, 4, 2, 1)
-    rc = lib.pvnet_vote_v3(None, 3, ms, None, vs, 1, 4, 4, 2, 8, C.c_float(0.99), 5, 100, 0, None, 0, None, None,
+    rc = lib.pvnet_vote_v3(None, 3, ms, None, vs, 1, 4, 4, 2, 8, C.c_float(0.99), 5, 100, 0, 0, None, 0, None, None,
                            None, 0, None)
     assert rc == -1
     rc = lib.pvnet_generate_hypothesis(None, None, None, None, 1, 1, 1, None)

@@ -1,0 +1,62 @@
+"""Turns rocprofv3's rocpd sqlite outputs (gpurun_out/prof_<tag>/) into the small text summaries kept under
+profiles/.   python tools/rocpd_summary.py gpurun_out/prof_r01a profiles/r01a"""
+import glob
+import os
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"\(VoteParams\)", "", name)
+    return name[:90]
+
+
+def kernel_stats(db):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
+                       "from kernels group by name order by sum(duration) desc").fetchall()
+    tot = sum(r[2] for r in rows)
+    out = ["%-92s %7s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%")]
+    for n, c, s, a, mn, mx in rows:
+        out.append("%-92s %7d %12.1f %10.2f %10.2f %10.2f %6.2f" % (short(n), c, s / 1e3, a / 1e3, mn / 1e3, mx / 1e3,
+                                                                    100 * s / tot))
+    return "\n".join(out)
+
+
+def pmc(db):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection "
+                       "group by kernel_name, counter_name order by kernel_name").fetchall()
+    out = ["%-92s %-22s %6s %16s %12s" % ("kernel", "counter", "n", "avg_value", "avg_dur_us")]
+    for k, c, n, v, d in rows:
+        if "at::native" in k or "rocclr" in k:
+            continue
+        out.append("%-92s %-22s %6d %16.2f %12.2f" % (short(k), c, n, v, d / 1e3))
+    return "\n".join(out)
+
+
+def main(src, dst):
+    parts = []
+    for db in sorted(glob.glob(os.path.join(src, "trace*", "*.db"))):
+        parts.append(f"== rocprofv3 --kernel-trace --stats  ({os.path.relpath(db, src)}) : per-kernel durations\n" +
+                     kernel_stats(db))
+    for db in sorted(glob.glob(os.path.join(src, "pmc*", "*.db"))):
+        parts.append(f"== rocprofv3 --pmc pass ({os.path.relpath(db, src)}) : average counter value per dispatch\n" +
+                     "   (FETCH_SIZE / WRITE_SIZE are KB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x\n"
+                     "    -- MI355X_MICROARCH.md 'HBM'; profiled passes run at lower clocks than un-profiled ones)\n" +
+                     pmc(db))
+    txt = "\n\n".join(parts) + "\n"
+    with open(dst + "_rocprof_summary.txt", "w") as f:
+        f.write(txt)
+    for j in ("bench.json", "trace_bench.json"):
+        p = os.path.join(src, j)
+        if os.path.exists(p):
+            with open(p) as f, open(dst + "_" + j, "w") as g:
+                g.write(f.read())
+    print(txt)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
