@@ -42,7 +42,7 @@ namespace {
 __device__ constexpr float kF1e6 = 0x1.0c6f7ap-20f;
 
 constexpr int CTRL_STRIDE = 8;
-enum { C_TN0 = 0, C_TN = 1, C_STATUS = 2, C_ITEM_BASE = 3, C_NCHUNKS = 4 };
+enum { C_TN0 = 0, C_TN = 1, C_STATUS = 2, C_ITEM_BASE = 3, C_NCHUNKS = 4, C_OX = 5, C_OY = 6 };
 
 constexpr int SEG_WORDS = 64;          // a segment = 64 words = 4096 pixels: the unit of K1 / K1b / K2 workgroups
 constexpr int K1_WORDS_PER_WAVE = SEG_WORDS / 4;  // 16 independent loads in flight per lane
@@ -127,6 +127,27 @@ __device__ __forceinline__ float vote_fast(float cx, float cy, float My, float n
     const float cr = fmaf(dy, nMx, dx * My);
     const float e = fmaf(dx, Tx, -fabsf(cr));
     return __builtin_amdgcn_fmed3f(fmaf(dy, Ty, e), 0.f, 1.f);  // folds into the fma's clamp bit
+}
+
+// The same margin with the subtraction of the pixel coordinate folded into per-pixel constants ("expanded form"):
+//     cr = hx*My - hy*Mx - Ec,  Ec = cx*My - cy*Mx          s = hx*Tx + hy*Ty - Ed - |cr|,  Ed = cx*Tx + cy*Ty
+// 5 VALU ops (4 fma + 1 sub with |.|) + 1 add -- one fewer than vote_fast.  Coordinates are taken relative to a
+// per-image origin inside the object (the raster-median foreground pixel), which keeps the cancellation small:
+// measured against float64 arithmetic on the benchmark data (tools/precision_study.py) this form flips 3e-8 of the
+// pair tests, vote_fast 1e-8, and the reference's own float32 sqrt/divide order 6e-7.
+// per-pixel constants as staged in LDS: a = (My, -Mx, -Ec, Tx) [ds_read_b128], b = (Ty, -Ed) [ds_read_b64]
+__device__ __forceinline__ void make_pixrec(float4 q, float2 tq, float ox, float oy, float4& a, float2& b) {
+    const float cx = q.x - ox, cy = q.y - oy;  // exact: integer pixel coordinates
+    const float My = q.z, nMx = q.w;
+    const float Ec = fmaf(cy, nMx, cx * My);
+    const float Ed = fmaf(cy, tq.y, cx * tq.x);
+    a = make_float4(My, nMx, -Ec, tq.x);
+    b = make_float2(tq.y, -Ed);
+}
+__device__ __forceinline__ float vote_expanded(float4 a, float2 b, float hx, float hy) {
+    const float cr = fmaf(hx, a.x, fmaf(hy, a.y, a.z));
+    const float t = b.y - fabsf(cr);
+    return __builtin_amdgcn_fmed3f(fmaf(hx, a.w, fmaf(hy, b.x, t)), 0.f, 1.f);  // clamp folds into the fma
 }
 
 __device__ __forceinline__ int wave_reduce_add(int v) {
@@ -342,6 +363,9 @@ __device__ __forceinline__ void plan_items(const VoteParams& P) {
             const bool skip = tn0 < P.min_num || tn <= 0;
             const int nch = skip ? 0 : (tn + P.chunk - 1) / P.chunk;
             P.ctrl[i * CTRL_STRIDE + C_NCHUNKS] = nch;
+            const int pm = skip ? 0 : P.pix[(size_t)i * P.cap + tn / 2];  // local origin for the expanded form
+            P.ctrl[i * CTRL_STRIDE + C_OX] = pm % P.w;
+            P.ctrl[i * CTRL_STRIDE + C_OY] = pm / P.w;
             if (skip) P.ctrl[i * CTRL_STRIDE + C_STATUS] |= PVNET_S_SKIPPED;
             n = ((nch + P.wg_s - 1) / P.wg_s) * P.vn * (P.hgroups / P.wg_g);  // workgroup items
         }
@@ -417,8 +441,8 @@ __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int G = P.wg_g, S = P.wg_s;  // G * S == 4 waves
     const int npx = S * P.chunk;
-    float4* s_rec = reinterpret_cast<float4*>(smem);
-    float2* s_tq = reinterpret_cast<float2*>(smem + (size_t)npx * sizeof(float4));
+    float4* s_a = reinterpret_cast<float4*>(smem);        // fast: (My, -Mx, -Ec, Tx)   literal: (x, y, ux, uy)
+    float2* s_b = reinterpret_cast<float2*>(s_a + npx);   // fast: (Ty, -Ed)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int32_t* __restrict__ ctrl = P.ctrl;
@@ -443,7 +467,8 @@ __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
         const size_t bk = (size_t)bi * P.vn + k;
         const int tpad = (tn + PAD - 1) / PAD * PAD;  // records up to tpad exist (sentinels past tn)
 
-        // ---- stage the chunk group's records in LDS
+        // ---- stage the chunk group's records in LDS (fast mode: expanded-form constants about the image origin)
+        const float ox = (float)ctrl[bi * CTRL_STRIDE + C_OX], oy = (float)ctrl[bi * CTRL_STRIDE + C_OY];
         __syncthreads();  // the previous item's readers are done
         for (int i = threadIdx.x; i < npx; i += 256) {
             const int p = cg * npx + i;
@@ -453,8 +478,15 @@ __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
                 q = P.rec[bk * P.cap + p];
                 if (!LITERAL) tq = P.tq[bk * P.cap + p];
             }
-            s_rec[i] = q;
-            if (!LITERAL) s_tq[i] = tq;
+            if (LITERAL) {
+                s_a[i] = q;
+            } else {
+                float4 a;
+                float2 b;
+                make_pixrec(q, tq, ox, oy, a, b);
+                s_a[i] = a;
+                s_b[i] = b;
+            }
         }
         __syncthreads();
 
@@ -467,29 +499,29 @@ __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
 #pragma unroll
         for (int j = 0; j < HPL; ++j) {
             const float2 hv = hb[j * 64 + lane];
-            hx[j] = hv.x;
-            hy[j] = hv.y;
+            hx[j] = LITERAL ? hv.x : hv.x - ox;
+            hy[j] = LITERAL ? hv.y : hv.y - oy;
             cnt[j] = 0.f;
         }
         const int n = (c * P.chunk + P.chunk <= tpad) ? P.chunk : tpad - c * P.chunk;  // multiple of PAD
-        const float4* sr = s_rec + sc * P.chunk;
-        const float2* st = s_tq + sc * P.chunk;
+        const float4* sa = s_a + sc * P.chunk;
+        const float2* sb = s_b + sc * P.chunk;
         for (int i = 0; i < n; i += NB) {
-            float4 q[NB];
-            float2 tq[NB];
+            float4 qa[NB];
+            float2 qb[NB];
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                q[u] = sr[i + u];
-                if (!LITERAL) tq[u] = st[i + u];
+                qa[u] = sa[i + u];
+                if (!LITERAL) qb[u] = sb[i + u];
             }
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
 #pragma unroll
                 for (int j = 0; j < HPL; ++j) {
                     if (LITERAL)
-                        cnt[j] += inlier_literal(q[u].x, q[u].y, q[u].z, q[u].w, hx[j], hy[j], P.thresh) ? 1.f : 0.f;
+                        cnt[j] += inlier_literal(qa[u].x, qa[u].y, qa[u].z, qa[u].w, hx[j], hy[j], P.thresh) ? 1.f : 0.f;
                     else
-                        cnt[j] += vote_fast(q[u].x, q[u].y, q[u].z, q[u].w, tq[u].x, tq[u].y, hx[j], hy[j]);
+                        cnt[j] += vote_expanded(qa[u], qb[u], hx[j], hy[j]);
                 }
             }
         }
@@ -572,6 +604,7 @@ __global__ __launch_bounds__(256) void select_refine_kernel(VoteParams P) {
     }
     // ---- inliers of the winner, normal equations centred on the winner, float64 (:579-594)
     const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
+    const float ox = (float)P.ctrl[bi * CTRL_STRIDE + C_OX], oy = (float)P.ctrl[bi * CTRL_STRIDE + C_OY];
     double a = 0, bb = 0, d = 0, r0 = 0, r1 = 0;
     int n = 0;
 #pragma unroll 4
@@ -583,7 +616,10 @@ __global__ __launch_bounds__(256) void select_refine_kernel(VoteParams P) {
             in = inlier_literal(q.x, q.y, u.x, u.y, wx, wy, P.thresh);
         } else {
             const float2 tq = P.tq[bk * P.cap + t];
-            in = vote_fast(q.x, q.y, q.z, q.w, tq.x, tq.y, wx, wy) > 0.5f;  // the very predicate that scored
+            float4 ra;
+            float2 rb;
+            make_pixrec(q, tq, ox, oy, ra, rb);
+            in = vote_expanded(ra, rb, wx - ox, wy - oy) > 0.5f;  // the very predicate that scored
         }
         const double wgt = in ? 1.0 : 0.0;  // predicated, not branched
         const double nx = (double)u.y * wgt, ny = -(double)u.x * wgt;  // normal = (dy, -dx) (:580-581)
@@ -842,7 +878,7 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     const long long units = (long long)b * vn * hgroups;
     int chunk = units >= 512 ? 256 : (units >= 128 ? 128 : 64);
     chunk = env_int("PVNET_SCORE_CHUNK", chunk);
-    if (chunk < PAD || chunk % PAD != 0 || chunk > 1024) return PVNET_E_UNSUPPORTED;  // LDS: 4 * 1024 * 24 B
+    if (chunk < PAD || chunk % PAD != 0 || chunk > 1024) return PVNET_E_UNSUPPORTED;  // LDS: 4 * 1024 * 32 B
     L->b = b; L->h = h; L->w = w; L->vn = vn; L->hn = hn;
     L->cap = (int)cap;
     L->words = (int)((npix + 63) / 64);
