@@ -47,7 +47,6 @@ enum { C_TN0 = 0, C_TN = 1, C_STATUS = 2, C_ITEM_BASE = 3, C_NCHUNKS = 4, C_OX =
 constexpr int SEG_WORDS = 64;          // a segment = 64 words = 4096 pixels: the unit of K1 / K1b / K2 workgroups
 constexpr int K1_WORDS_PER_WAVE = SEG_WORDS / 4;  // 16 independent loads in flight per lane
 constexpr int K2_WORDS_PER_BLOCK = SEG_WORDS;
-constexpr int K2_KG = 3;               // key-points per compaction block (grid.z = ceil(vn / 3))
 constexpr int PAD = 8;                 // scoring consumes records 8 at a time; tails are padded with sentinels
 
 struct VoteParams {
@@ -65,6 +64,7 @@ struct VoteParams {
     uint32_t flags;
     int32_t* ctrl;
     int32_t* seg;
+    int32_t* seg0;
     int nseg;
     uint64_t* bits;
     int32_t* pix;
@@ -216,8 +216,8 @@ __global__ __launch_bounds__(256) void mask_bits_kernel(VoteParams P) {
     __syncthreads();
     if (threadIdx.x == 0) {
         const int t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        P.seg[bi * P.nseg + blockIdx.x] = t;  // foreground pixels of this 4096-pixel segment
-        if (t) atomicAdd(&P.ctrl[bi * CTRL_STRIDE + C_TN0], t);
+        P.seg[bi * P.nseg + blockIdx.x] = t;   // foreground pixels of this 4096-pixel segment (thinned by K1b)
+        P.seg0[bi * P.nseg + blockIdx.x] = t;  // ... as the mask has them (tn0 = their sum)
     }
 }
 
@@ -226,8 +226,14 @@ __global__ __launch_bounds__(256) void mask_bits_kernel(VoteParams P) {
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void subsample_kernel(VoteParams P) {
     const int bi = blockIdx.y;
-    const int tn0 = P.ctrl[bi * CTRL_STRIDE + C_TN0];
-    if (tn0 <= P.max_num) return;  // wave-uniform: the common case costs one scalar load
+    // tn0 = sum of this image's segment counts; every wave reduces it for itself (no barrier, no atomics).
+    // The counts this launch reads are K1's; blocks of this launch overwrite only their OWN segment's count,
+    // and only after every wave of the block has passed this point (the barrier below) -- but other blocks may
+    // already have thinned theirs, so the unthinned total is kept by K1 in a second array.
+    int tn0 = 0;
+    for (int j = threadIdx.x & 63; j < P.nseg; j += 64) tn0 += P.seg0[bi * P.nseg + j];
+    tn0 = __builtin_amdgcn_readfirstlane(wave_reduce_add(tn0));
+    if (tn0 <= P.max_num) return;  // wave-uniform: the common case costs a few loads
     const float p = (float)P.max_num / (float)tn0;
     const double t = ceil((double)p * 4294967296.0);
     if (t >= 4294967296.0) return;
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(256) void subsample_kernel(VoteParams P) {
 // ------------------------------------------------------------------------------------------------------------
 // K2: order-preserving compaction + direction gather          (ransac_voting_gpu.py:542-546)
 // ------------------------------------------------------------------------------------------------------------
-template <bool LITERAL>
+template <bool LITERAL, int K2_KG>  // K2_KG key-points per block: grid.z = ceil(vn / K2_KG)
 __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
     const int bi = blockIdx.y;
     const int w0 = blockIdx.x * K2_WORDS_PER_BLOCK;
@@ -292,49 +298,84 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
     const int base = s_red[0] + s_red[1] + s_red[2] + s_red[3];
     const int usable = P.cap - PAD;
 
-    // blockIdx.z selects a group of K2_KG key-points: 3x the blocks in flight and 2*K2_KG independent gathers
-    // per lane before the first use (the stage is latency-bound: ~13 active segments per 480x640 image)
+    // One thread per KEPT pixel (not per mask bit): thread t of the segment finds the word holding its pixel by a
+    // binary search over the 64 word offsets (LDS) and the bit by a popcount bisection, so every lane does useful
+    // work and consecutive lanes gather consecutive (raster-adjacent) addresses.  blockIdx.z selects a group of
+    // K2_KG key-points; two pixels per thread are in flight before the first use (the stage is latency-bound).
     const int k0 = blockIdx.z * K2_KG;
-    for (int jj = wave; jj < K2_WORDS_PER_BLOCK; jj += 4) {  // interleaved: a mask row alternates full/empty words
-        const unsigned long long word = s_word[jj];
-        if (word == 0) continue;  // wave-uniform: rows without foreground cost nothing
-        const bool bit = (word >> lane) & 1ull;
-        const int pos = base + s_woff[jj] + __popcll(word & ((1ull << lane) - 1ull));
-        if (bit && pos < usable) {
-            const int p = (w0 + jj) * 64 + lane;
-            const int y = p / P.w, x = p - y * P.w;
-            if (k0 == 0) P.pix[(size_t)bi * P.cap + pos] = p;
-            const float* v = P.vertex + (int64_t)bi * P.vs0 + (int64_t)y * P.vs1 + (int64_t)x * P.vs2;
-            float ux[K2_KG], uy[K2_KG];
+    const int T = s_total;
+    auto locate = [&](int t, int& pos, int& p) {
+        int lo = 0;
 #pragma unroll
-            for (int kk = 0; kk < K2_KG; ++kk) {
-                const int k = (k0 + kk < P.vn) ? k0 + kk : P.vn - 1;  // clamp: loads stay in bounds, unconditional
-                ux[kk] = v[(int64_t)k * P.vs3];
-                uy[kk] = v[(int64_t)k * P.vs3 + P.vs4];
-            }
+        for (int st = 32; st > 0; st >>= 1)
+            if (lo + st < K2_WORDS_PER_BLOCK && s_woff[lo + st] <= t) lo += st;
+        unsigned long long wd = s_word[lo];
+        int r = t - s_woff[lo], bitpos = 0;
 #pragma unroll
-            for (int kk = 0; kk < K2_KG; ++kk) {
-                if (k0 + kk >= P.vn) break;
-                const size_t o = ((size_t)bi * P.vn + k0 + kk) * P.cap + pos;
-                P.dir[o] = make_float2(ux[kk], uy[kk]);
-                if (LITERAL) {
-                    P.rec[o] = make_float4((float)x, (float)y, ux[kk], uy[kk]);
-                } else {
-                    const float n1 = __builtin_sqrtf(fmaf(uy[kk], uy[kk], ux[kk] * ux[kk]));
-                    const float sc = (n1 <= kF1e6) ? 0.f : kVoteScale;  // zero direction never votes (:121)
-                    const float Mx = ux[kk] * sc, My = uy[kk] * sc;
-                    P.rec[o] = make_float4((float)x, (float)y, My, -Mx);
-                    P.tq[o] = make_float2(P.tau * Mx, P.tau * My);
-                }
+        for (int st = 32; st > 0; st >>= 1) {
+            const int c = __popcll((wd >> bitpos) & ((1ull << st) - 1ull));
+            if (r >= c) { bitpos += st; r -= c; }
+        }
+        pos = base + t;
+        p = (w0 + lo) * 64 + bitpos;
+    };
+    auto emit = [&](int pos, int x, int y, const float* ux, const float* uy) {
+#pragma unroll
+        for (int kk = 0; kk < K2_KG; ++kk) {
+            if (k0 + kk >= P.vn) break;
+            const size_t o = ((size_t)bi * P.vn + k0 + kk) * P.cap + pos;
+            P.dir[o] = make_float2(ux[kk], uy[kk]);
+            if (LITERAL) {
+                P.rec[o] = make_float4((float)x, (float)y, ux[kk], uy[kk]);
+            } else {
+                const float n1 = __builtin_sqrtf(fmaf(uy[kk], uy[kk], ux[kk] * ux[kk]));
+                const float sc = (n1 <= kF1e6) ? 0.f : kVoteScale;  // zero direction never votes (:121)
+                const float Mx = ux[kk] * sc, My = uy[kk] * sc;
+                P.rec[o] = make_float4((float)x, (float)y, My, -Mx);
+                P.tq[o] = make_float2(P.tau * Mx, P.tau * My);
             }
+        }
+    };
+    for (int t0 = threadIdx.x; t0 < T; t0 += 512) {
+        const int t1 = t0 + 256;
+        const bool has1 = t1 < T;
+        int pos0, p0, pos1 = 0, p1 = 0;
+        locate(t0, pos0, p0);
+        if (has1) locate(t1, pos1, p1);
+        const int y0 = p0 / P.w, x0 = p0 - y0 * P.w;
+        const int y1 = p1 / P.w, x1 = p1 - y1 * P.w;
+        const float* v0 = P.vertex + (int64_t)bi * P.vs0 + (int64_t)y0 * P.vs1 + (int64_t)x0 * P.vs2;
+        const float* v1 = P.vertex + (int64_t)bi * P.vs0 + (int64_t)y1 * P.vs1 + (int64_t)x1 * P.vs2;
+        float ux0[K2_KG], uy0[K2_KG], ux1[K2_KG], uy1[K2_KG];
+#pragma unroll
+        for (int kk = 0; kk < K2_KG; ++kk) {
+            const int k = (k0 + kk < P.vn) ? k0 + kk : P.vn - 1;  // clamp: loads stay in bounds, unconditional
+            ux0[kk] = v0[(int64_t)k * P.vs3];
+            uy0[kk] = v0[(int64_t)k * P.vs3 + P.vs4];
+            ux1[kk] = v1[(int64_t)k * P.vs3];  // (p1 = 0 when there is no second pixel: a valid address)
+            uy1[kk] = v1[(int64_t)k * P.vs3 + P.vs4];
+        }
+        if (pos0 < usable) {
+            if (k0 == 0) P.pix[(size_t)bi * P.cap + pos0] = p0;
+            emit(pos0, x0, y0, ux0, uy0);
+        }
+        if (has1 && pos1 < usable) {
+            if (k0 == 0) P.pix[(size_t)bi * P.cap + pos1] = p1;
+            emit(pos1, x1, y1, ux1, uy1);
         }
     }
     if (last) {  // the block that owns the last segment knows the total
         const int total = base + s_total;
         const int tn = total < usable ? total : usable;
-        if (threadIdx.x == 0 && k0 == 0) {
-            P.ctrl[bi * CTRL_STRIDE + C_TN] = tn;
-            if (total > usable) P.ctrl[bi * CTRL_STRIDE + C_STATUS] = PVNET_S_OVERFLOW;
+        if (k0 == 0 && wave == 0) {  // nothing zero-fills ctrl: this block owns tn0 / tn / status of its image
+            int t0 = 0;
+            for (int j = lane; j < P.nseg; j += 64) t0 += P.seg0[bi * P.nseg + j];
+            t0 = wave_reduce_add(t0);
+            if (lane == 0) {
+                P.ctrl[bi * CTRL_STRIDE + C_TN0] = t0;
+                P.ctrl[bi * CTRL_STRIDE + C_TN] = tn;
+                P.ctrl[bi * CTRL_STRIDE + C_STATUS] = total > usable ? PVNET_S_OVERFLOW : 0;
+            }
         }
         const int tpad = (tn + PAD - 1) / PAD * PAD;  // sentinel records: zero direction never votes
         const int kn = (k0 + K2_KG < P.vn ? k0 + K2_KG : P.vn) - k0;
@@ -389,6 +430,10 @@ __device__ __forceinline__ void plan_items(const VoteParams& P) {
 // K3: hypotheses                                               (ransac_voting_gpu.py:547,554; kernel.cu:11-49)
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
+    if (blockIdx.x == gridDim.x - 1) {  // one extra block per image row; the first of them plans the work items
+        if (blockIdx.y == 0) plan_items(P);  // consumed by the next launches only
+        return;
+    }
     const int bi = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
@@ -417,7 +462,6 @@ __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
     }
     P.hyp[((size_t)bi * P.vn + k) * P.hn_pad + h] = make_float2(hx, hy);
     }
-    if (blockIdx.x == 0 && blockIdx.y == 0) plan_items(P);  // consumed by the next launches only
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -534,17 +578,19 @@ __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
 // ------------------------------------------------------------------------------------------------------------
 // K5: arg-max + least-squares refinement                        (ransac_voting_gpu.py:561-569, 579-595, 503-512)
 // ------------------------------------------------------------------------------------------------------------
+constexpr int RT = 512;  // threads per (image, key-point) (measured: 256 -> 19 us, 1024 -> 23 us at batch 32)
+constexpr int RW = RT / 64;
 template <bool LITERAL>
-__global__ __launch_bounds__(256) void select_refine_kernel(VoteParams P) {
+__global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
     const int k = blockIdx.x, bi = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t bk = (size_t)bi * P.vn + k;
     const int nch = P.ctrl[bi * CTRL_STRIDE + C_NCHUNKS];
     int status = P.ctrl[bi * CTRL_STRIDE + C_STATUS];
 
-    __shared__ unsigned long long s_best[4];
-    __shared__ double s_sum[4][5];
-    __shared__ int s_n[4];
+    __shared__ unsigned long long s_best[RW];
+    __shared__ double s_sum[RW][5];
+    __shared__ int s_n[RW];
 
     if (nch == 0) {  // fewer than min_num foreground pixels: zeros (:531-534)
         if (threadIdx.x < 2) P.out[bk * 2 + threadIdx.x] = 0.f;
@@ -553,12 +599,12 @@ __global__ __launch_bounds__(256) void select_refine_kernel(VoteParams P) {
             P.win[bk * 2] = 0;
             P.win[bk * 2 + 1] = 0;
         }
-        for (int h = threadIdx.x; h < P.hn; h += 256) P.counts[bk * P.hn_pad + h] = 0;
+        for (int h = threadIdx.x; h < P.hn; h += RT) P.counts[bk * P.hn_pad + h] = 0;
         return;
     }
     // ---- counts = sum over chunks; winner = first maximum (:561-562)
     unsigned long long best = 0;
-    for (int h = threadIdx.x; h < P.hn; h += 256) {
+    for (int h = threadIdx.x; h < P.hn; h += RT) {
         const uint16_t* pp = P.partial + bk * P.max_chunks * P.hn_pad + h;
         int s0 = 0, s1 = 0, s2 = 0, s3 = 0;  // four independent chains: chunk loads overlap instead of serialising
         int c = 0;
@@ -579,7 +625,7 @@ __global__ __launch_bounds__(256) void select_refine_kernel(VoteParams P) {
     __syncthreads();
     best = s_best[0];
 #pragma unroll
-    for (int i = 1; i < 4; ++i) best = s_best[i] > best ? s_best[i] : best;
+    for (int i = 1; i < RW; ++i) best = s_best[i] > best ? s_best[i] : best;
     const int wcnt = (int)(best >> 32);
     const int widx = (int)(0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull));
     float wx = 0.f, wy = 0.f;  // all_win_pts starts at zero and only a strictly larger ratio replaces it (:548-569)
@@ -608,7 +654,7 @@ __global__ __launch_bounds__(256) void select_refine_kernel(VoteParams P) {
     double a = 0, bb = 0, d = 0, r0 = 0, r1 = 0;
     int n = 0;
 #pragma unroll 4
-    for (int t = threadIdx.x; t < tn; t += 256) {
+    for (int t = threadIdx.x; t < tn; t += RT) {
         const float4 q = P.rec[bk * P.cap + t];
         const float2 u = P.dir[bk * P.cap + t];
         bool in;
@@ -645,7 +691,7 @@ __global__ __launch_bounds__(256) void select_refine_kernel(VoteParams P) {
     if (threadIdx.x == 0) {
         a = bb = d = r0 = r1 = 0;
         n = 0;
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < RW; ++i) {
             a += s_sum[i][0]; bb += s_sum[i][1]; d += s_sum[i][2]; r0 += s_sum[i][3]; r1 += s_sum[i][4];
             n += s_n[i];
         }
@@ -752,7 +798,6 @@ int launch_score(const VoteParams& P, dim3 grid, hipStream_t s) {
 int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
     const bool literal = (P.flags & PVNET_F_LITERAL) != 0;
     auto mark = [&](int i) -> hipError_t { return ev ? hipEventRecord(ev[i], s) : hipSuccess; };
-    PV_HIP(hipMemsetAsync(P.ctrl, 0, sizeof(int32_t) * CTRL_STRIDE * (size_t)(P.b + 1), s));
     PV_HIP(mark(0));
     {   // K1
         dim3 grid(P.nseg, P.b);
@@ -773,15 +818,18 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
         PV_HIP(mark(2));
     }
     {   // K2
-        dim3 grid(P.nseg, P.b, (P.vn + K2_KG - 1) / K2_KG);
-        if (literal) hipLaunchKernelGGL(compact_kernel<true>, grid, dim3(256), 0, s, P);
-        else hipLaunchKernelGGL(compact_kernel<false>, grid, dim3(256), 0, s, P);
+        const int kg = env_int("PVNET_COMPACT_KG", 3);
+        dim3 grid(P.nseg, P.b, (P.vn + kg - 1) / kg);
+        if (literal) hipLaunchKernelGGL((compact_kernel<true, 3>), dim3(P.nseg, P.b, (P.vn + 2) / 3), dim3(256), 0, s, P);
+        else if (kg == 1) hipLaunchKernelGGL((compact_kernel<false, 1>), grid, dim3(256), 0, s, P);
+        else if (kg == 9) hipLaunchKernelGGL((compact_kernel<false, 9>), grid, dim3(256), 0, s, P);
+        else hipLaunchKernelGGL((compact_kernel<false, 3>), dim3(P.nseg, P.b, (P.vn + 2) / 3), dim3(256), 0, s, P);
         PV_LAUNCH_CHECK();
         PV_HIP(mark(3));
     }
     PV_HIP(mark(4));  // (the work-item plan is computed by block (0,0) of the hypothesis launch)
     {   // K3
-        dim3 grid((P.hn * P.vn + 255) / 256, P.b);
+        dim3 grid((P.hn * P.vn + 255) / 256 + 1, P.b);
         hipLaunchKernelGGL(hypothesis_kernel, grid, dim3(256), 0, s, P);
         PV_LAUNCH_CHECK();
         PV_HIP(mark(5));
@@ -800,8 +848,8 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
     }
     {   // K5
         dim3 grid(P.vn, P.b);
-        if (literal) hipLaunchKernelGGL(select_refine_kernel<true>, grid, dim3(256), 0, s, P);
-        else hipLaunchKernelGGL(select_refine_kernel<false>, grid, dim3(256), 0, s, P);
+        if (literal) hipLaunchKernelGGL(select_refine_kernel<true>, grid, dim3(RT), 0, s, P);
+        else hipLaunchKernelGGL(select_refine_kernel<false>, grid, dim3(RT), 0, s, P);
         PV_LAUNCH_CHECK();
         PV_HIP(mark(7));
     }
@@ -834,6 +882,7 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     P.min_num = min_num; P.max_num = max_num; P.seed = seed; P.image_base = image_base; P.idxs = idxs; P.flags = flags;
     P.ctrl = reinterpret_cast<int32_t*>(base + L.off_ctrl);
     P.seg = reinterpret_cast<int32_t*>(base + L.off_seg);
+    P.seg0 = P.seg + (size_t)L.b * L.nseg;
     P.nseg = L.nseg;
     P.bits = reinterpret_cast<uint64_t*>(base + L.off_bits);
     P.pix = reinterpret_cast<int32_t*>(base + L.off_pix);
@@ -893,7 +942,7 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     L->nseg = (L->words + SEG_WORDS - 1) / SEG_WORDS;
     L->off_ctrl = take(sizeof(int32_t) * CTRL_STRIDE * (size_t)(b + 1));
-    L->off_seg = take(sizeof(int32_t) * (size_t)b * L->nseg);
+    L->off_seg = take(sizeof(int32_t) * 2 * (size_t)b * L->nseg);  // thinned counts, then the mask's own
     L->off_bits = take(sizeof(uint64_t) * (size_t)b * L->words);
     L->off_pix = take(sizeof(int32_t) * (size_t)b * cap);
     L->off_rec = take(sizeof(float) * 4 * (size_t)b * vn * cap);
