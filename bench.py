@@ -67,6 +67,20 @@ def make_inputs(rank, nbuf, radius, noisy, dev):
     return sets
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_traffic.json, written
+    by tools/rocpd_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes); None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"][kernel]
+        return int((2.0 * k.get("fetch_kb", 0.0) + k.get("write_kb", 0.0)) * 1024)  # FETCH_SIZE x2: gfx950 correction
+    except (KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(sets, seconds):
     """the oracle (plain-C port, OpenMP) on a bounded sample of the same workload -- reported, never the target"""
     from oracle import cref
@@ -165,7 +179,8 @@ def main():
                        "input_sets_cycled": len(sets), "parallelism": f"images sharded over {world} GPU(s)"},
             "roofline": {"kernel": "score_kernel", "bound": "valu", "achieved": FLOP_PER_PAIR * pairs / score_s / 1e12,
                          "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": FLOP_PER_PAIR * pairs / score_s / 1e12 / PEAK_F32_TFLOPS, "traffic": None,
+                         "frac": FLOP_PER_PAIR * pairs / score_s / 1e12 / PEAK_F32_TFLOPS,
+                         "traffic": measured_traffic("score_kernel"),
                          "avg_launch_ms": stage_ms["score"], "pair_tests_per_launch": pairs,
                          "note": "fp32 vector peak = dense f32 MFMA rate on gfx950; no MFMA used (irregular "
                                  "gather/reduce); 12 flop per pair test as SURVEY.md 8d counts them"},

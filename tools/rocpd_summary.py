@@ -47,6 +47,23 @@ def main(src, dst):
                      "   (FETCH_SIZE / WRITE_SIZE are KB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x\n"
                      "    -- MI355X_MICROARCH.md 'HBM'; profiled passes run at lower clocks than un-profiled ones)\n" +
                      pmc(db))
+    # per-launch HBM traffic of every kernel of the path (for bench.py's roofline.traffic)
+    traffic = {}
+    for kind in ("fetch", "write"):
+        for db in glob.glob(os.path.join(src, f"pmc_{kind}", "*.db")):
+            cur = sqlite3.connect(db).cursor()
+            for k, v in cur.execute("select kernel_name, avg(value) from counters_collection where counter_name=? "
+                                    "group by kernel_name", (kind.upper() + "_SIZE",)):
+                m = re.search(r"(\w+_kernel)", k)
+                if m:
+                    traffic.setdefault(m.group(1), {})[kind + "_kb"] = v
+    if traffic:
+        import json
+        with open(dst + "_traffic.json", "w") as f:
+            json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), average per dispatch, KB",
+                       "note": "gfx950 FETCH_SIZE counts wide coalesced reads at 1/2 (MI355X_MICROARCH.md, HBM): "
+                               "bench.py doubles fetch_kb",
+                       "kernels": traffic}, f, indent=1)
     txt = "\n\n".join(parts) + "\n"
     with open(dst + "_rocprof_summary.txt", "w") as f:
         f.write(txt)
