@@ -125,6 +125,19 @@ int pvnet_vote_v3_profiled(const void* mask, int mask_dtype, const int64_t mask_
                            float* out_kpts, int32_t* out_status,
                            void* workspace, size_t workspace_bytes, void* stream, float* stage_ms);
 
+/* Epilogues of the reference's sibling functions.  Both run on the WORKSPACE of a preceding pvnet_vote_v3 call with
+ * the same (b,h,w,vn,hn,max_num) on the same stream (they read its compacted pixel lists, hypotheses and counts).
+ *
+ * pvnet_vote_confidence: ransac_voting_layer_v5's second output (ransac_voting_gpu.py:846-850): out_conf[b,vn] =
+ *   fraction of the image's kept pixels whose direction points at kpts[b,vn,2] within `thresh` (0.999 there). */
+int pvnet_vote_confidence(const float* kpts, float thresh, float* out_conf, int b, int h, int w, int vn, int hn,
+                          int max_num, void* workspace, size_t workspace_bytes, void* stream);
+/* pvnet_vote_distribution: estimate_voting_distribution_with_mean's epilogue (ransac_voting_gpu.py:389-404):
+ *   out_cov[b,vn,2,2] = sum_h w_h (hyp_h - mean)(hyp_h - mean)^T / (sum_h w_h + 1e-3), w_h = inlier ratio of
+ *   hypothesis h where it is within 0.1 of the key-point's best ratio, else 0; mean [b,vn,2]. */
+int pvnet_vote_distribution(const float* mean, float* out_cov, int b, int h, int w, int vn, int hn, int max_num,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* Op-level entry points with the reference extension's tensor layouts.
  * direct [tn,vn,2] f32, coords [tn,2] f32, idxs [hn,vn,2] i32 -> hypo_pts [hn,vn,2] f32 (fully written; degenerate
  * pairs give (0,0) as the reference's at::zeros + early return do, ransac_voting_kernel.cu:42-43,75). */

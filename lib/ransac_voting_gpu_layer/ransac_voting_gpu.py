@@ -12,5 +12,7 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 
-from pvnet_amd.voting import ransac_voting_layer_v3  # noqa: E402,F401
+from pvnet_amd.voting import (estimate_voting_distribution_with_mean, ransac_motion_voting,  # noqa: E402,F401
+                              ransac_voting_layer_v3, ransac_voting_layer_v5)
+from pvnet_amd.voting import generate_hypothesis_counts as generate_hypothesis  # noqa: E402,F401  (:983-1034)
 from pvnet_amd import voting as ransac_voting  # noqa: E402,F401  (the op module the reference imports at :2)

@@ -318,3 +318,33 @@ def vote_confidence(mask, vertex, pts, thresh=0.999, dtype=np.float64):
         c = voting_counts(direct, coords, pts[bi][None].astype(dtype), thresh, dtype)[0]
         conf[bi] = c.astype(np.float32) / np.float32(coords.shape[0])
     return conf
+
+
+def estimate_voting_distribution_with_mean(mask, vertex, mean, hn, inlier_thresh=0.99, min_num=5, max_num=30000, *,
+                                           idxs=None, seed=0, dtype=np.float64):
+    """ransac_voting_gpu.py:333-406 with ONE draw of ``hn`` pixel pairs per key-point (the reference draws
+    hn/256 rounds of 256 independent pairs).  Returns cov [b,vn,2,2] float64."""
+    mask = np.asarray(mask)
+    vertex = np.asarray(vertex)
+    b, h, w, vn, _ = vertex.shape
+    cov = np.zeros((b, vn, 2, 2))
+    for bi in range(b):
+        fg = foreground(mask[bi])
+        tn0 = int(fg.sum())
+        if tn0 < min_num:  # :343-349  zero hypotheses with ratio one
+            hyp = np.zeros((hn, vn, 2))
+            ratio = np.ones((hn, vn))
+        else:
+            if tn0 > max_num:
+                fg = fg & subsample_keep(seed, bi, h * w, max_num, tn0).reshape(h, w)
+            coords, direct = compact(fg, vertex[bi])
+            tn = coords.shape[0]
+            ix = draw_idxs(seed, bi, hn, vn, tn) if idxs is None else np.asarray(idxs)[bi]
+            hyp = generate_hypothesis(direct, coords, ix.astype(np.int64), dtype)
+            ratio = voting_counts(direct, coords, hyp, inlier_thresh, dtype).astype(np.float32) / np.float32(tn)
+        for k in range(vn):
+            r = ratio[:, k].astype(np.float64).copy()
+            r[ratio[:, k] < np.float32(ratio[:, k].max()) - np.float32(0.1)] = 0.0  # :394-395
+            d = hyp[:, k].astype(np.float64) - np.asarray(mean)[bi, k][None]
+            cov[bi, k] = (d * r[:, None]).T @ d / (r.sum() + 1e-3)  # :398-401
+    return cov

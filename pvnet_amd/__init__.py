@@ -6,7 +6,8 @@ Public surface (mirrors lib/ransac_voting_gpu_layer of zju3dv/pvnet):
 The compute lives in libpvnet_vote.so (HIP, C ABI in include/pvnet_vote.h); build it with
 `python -m pvnet_amd.build`.
 """
-from .voting import (generate_hypothesis, load_library, ransac_voting_layer_v3,  # noqa: F401
-                     voting_for_hypothesis)
+from .voting import (estimate_voting_distribution_with_mean, generate_hypothesis,  # noqa: F401
+                     generate_hypothesis_counts, load_library, ransac_motion_voting, ransac_voting_layer_v3,
+                     ransac_voting_layer_v5, voting_for_hypothesis)
 
 __all__ = ["ransac_voting_layer_v3", "generate_hypothesis", "voting_for_hypothesis", "load_library"]

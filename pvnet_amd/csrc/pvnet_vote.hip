@@ -710,6 +710,78 @@ __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// epilogues of the reference's sibling functions, run on the workspace a pvnet_vote_v3 call left behind
+// ------------------------------------------------------------------------------------------------------------
+// ransac_voting_layer_v5's extra output (ransac_voting_gpu.py:846-850): fraction of the image's kept pixels that
+// vote (literal float32 test, threshold `thresh`, 0.999 in the reference) for the given points.
+__global__ __launch_bounds__(256) void confidence_kernel(VoteParams P, const float* __restrict__ pts, float thresh,
+                                                         float* __restrict__ conf) {
+    const int k = blockIdx.x, bi = blockIdx.y;
+    const size_t bk = (size_t)bi * P.vn + k;
+    const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
+    const bool live = P.ctrl[bi * CTRL_STRIDE + C_NCHUNKS] > 0;
+    const float px = pts[bk * 2], py = pts[bk * 2 + 1];
+    int n = 0;
+    if (live)
+        for (int t = threadIdx.x; t < tn; t += 256) {
+            const int p = P.pix[(size_t)bi * P.cap + t];
+            const int y = p / P.w;
+            const float2 u = P.dir[bk * P.cap + t];
+            n += inlier_literal((float)(p - y * P.w), (float)y, u.x, u.y, px, py, thresh) ? 1 : 0;
+        }
+    n = wave_reduce_add(n);
+    __shared__ int s_n[4];
+    if ((threadIdx.x & 63) == 0) s_n[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) conf[bk] = live ? (float)(s_n[0] + s_n[1] + s_n[2] + s_n[3]) / (float)tn : 0.f;
+}
+
+// estimate_voting_distribution_with_mean's epilogue (ransac_voting_gpu.py:389-404): ratio-weighted 2x2 covariance
+// of the hypotheses about `mean`, weights = inlier ratio where it is within 0.1 of the key-point's best, else 0.
+__global__ __launch_bounds__(256) void distribution_kernel(VoteParams P, const float* __restrict__ mean,
+                                                           float* __restrict__ cov) {
+    const int k = blockIdx.x, bi = blockIdx.y;
+    const size_t bk = (size_t)bi * P.vn + k;
+    const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
+    const bool live = P.ctrl[bi * CTRL_STRIDE + C_NCHUNKS] > 0;
+    const float mx = mean[bk * 2], my = mean[bk * 2 + 1];
+    // skipped image: the reference substitutes zero hypotheses with ratio one (:343-349)
+    const float best = live ? (float)P.win[bk * 2 + 1] / (float)tn : 1.f;
+    const float cut = best - 0.1f;  // :394
+    double sxx = 0, sxy = 0, syy = 0, sw = 0;
+    for (int h = threadIdx.x; h < P.hn; h += 256) {
+        float r = 1.f, hx = 0.f, hy = 0.f;
+        if (live) {
+            r = (float)P.counts[bk * P.hn_pad + h] / (float)tn;  // :378-379
+            const float2 hv = P.hyp[bk * P.hn_pad + h];
+            hx = hv.x;
+            hy = hv.y;
+        }
+        if (r < cut) r = 0.f;  // :395
+        const double dx = (double)hx - mx, dy = (double)hy - my;
+        sxx += r * dx * dx;
+        sxy += r * dx * dy;
+        syy += r * dy * dy;
+        sw += r;
+    }
+    sxx = wave_reduce_add(sxx); sxy = wave_reduce_add(sxy); syy = wave_reduce_add(syy); sw = wave_reduce_add(sw);
+    __shared__ double s_acc[4][4];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_acc[wave][0] = sxx; s_acc[wave][1] = sxy; s_acc[wave][2] = syy; s_acc[wave][3] = sw; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) a[j] += s_acc[i][j];
+        const double den = a[3] + 1e-3;  // :401
+        cov[bk * 4 + 0] = (float)(a[0] / den);
+        cov[bk * 4 + 1] = (float)(a[1] / den);
+        cov[bk * 4 + 2] = (float)(a[1] / den);
+        cov[bk * 4 + 3] = (float)(a[2] / den);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // op-level kernels with the reference extension's layouts
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void op_generate_hypothesis_kernel(const float* __restrict__ direct,
@@ -1004,6 +1076,38 @@ int pvnet_vote_v3_profiled(const void* mask, int mask_dtype, const int64_t mask_
         }
     for (int i = 0; i <= PVNET_NUM_STAGES; ++i) (void)hipEventDestroy(ev[i]);
     return rc;
+}
+
+static int params_for_workspace(VoteParams& P, int b, int h, int w, int vn, int hn, int max_num, void* ws,
+                                size_t ws_bytes) {
+    static const int64_t ms[3] = {0, 0, 1}, vs[5] = {0, 0, 0, 0, 1};
+    static float dummy;
+    return fill_params(P, &dummy, PVNET_MASK_U8, ms, &dummy, vs, b, h, w, vn, hn, 0.5f, 0, max_num, 0, 0, nullptr, 0,
+                       &dummy, nullptr, ws, ws_bytes);
+}
+
+int pvnet_vote_confidence(const float* kpts, float thresh, float* out_conf, int b, int h, int w, int vn, int hn,
+                          int max_num, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!kpts || !out_conf) return PVNET_E_BADARG;
+    VoteParams P;
+    int rc = params_for_workspace(P, b, h, w, vn, hn, max_num, workspace, workspace_bytes);
+    if (rc) return rc;
+    hipLaunchKernelGGL(confidence_kernel, dim3(vn, b), dim3(256), 0, static_cast<hipStream_t>(stream), P, kpts, thresh,
+                       out_conf);
+    PV_LAUNCH_CHECK();
+    return 0;
+}
+
+int pvnet_vote_distribution(const float* mean, float* out_cov, int b, int h, int w, int vn, int hn, int max_num,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    if (!mean || !out_cov) return PVNET_E_BADARG;
+    VoteParams P;
+    int rc = params_for_workspace(P, b, h, w, vn, hn, max_num, workspace, workspace_bytes);
+    if (rc) return rc;
+    hipLaunchKernelGGL(distribution_kernel, dim3(vn, b), dim3(256), 0, static_cast<hipStream_t>(stream), P, mean,
+                       out_cov);
+    PV_LAUNCH_CHECK();
+    return 0;
 }
 
 int pvnet_generate_hypothesis(const float* direct, const float* coords, const int32_t* idxs, float* hypo_pts, int tn,

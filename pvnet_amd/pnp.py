@@ -1,0 +1,141 @@
+"""Host-side pose recovery from the voted 2-D key-points -- SURVEY.md section 8(f) row 1.
+
+The reference does this on the host as well: ``pnp`` = ``cv2.solvePnP(..., SOLVEPNP_ITERATIVE)``
+(lib/utils/evaluation_utils.py:19-52), ``uncertainty_pnp`` = P3P initialisation + a Ceres Levenberg-Marquardt on
+2x2-weighted reprojection residuals (lib/utils/extend_utils/extend_utils.py:63-114,
+lib/utils/extend_utils/src/uncertainty_pnp.cpp:7-92).  Neither OpenCV nor Ceres exists in this image, and this
+is a 9-point, 6-parameter problem: numpy + scipy.  Same algorithm class as OpenCV's ITERATIVE flag: a DLT
+initialisation followed by Levenberg-Marquardt on the reprojection error over (Rodrigues vector, translation).
+Also the pose metrics of ``Evaluator`` (evaluation_utils.py:75-134).  Not on the GPU hot path.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.optimize import least_squares
+
+LINEMOD_K = np.array([[572.4114, 0., 325.2611], [0., 573.57043, 242.04899], [0., 0., 1.]])  # base_utils.py:241-243
+
+
+def rodrigues(rvec: np.ndarray) -> np.ndarray:
+    """axis-angle vector -> 3x3 rotation (cv2.Rodrigues)."""
+    rvec = np.asarray(rvec, np.float64).reshape(3)
+    th = np.linalg.norm(rvec)
+    if th < 1e-12:
+        return np.eye(3) + _skew(rvec)
+    k = rvec / th
+    K = _skew(k)
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+
+
+def rodrigues_inv(R: np.ndarray) -> np.ndarray:
+    c = np.clip((np.trace(R) - 1) / 2, -1, 1)
+    th = np.arccos(c)
+    if th < 1e-12:
+        return np.zeros(3)
+    if np.pi - th < 1e-6:  # near pi: take the axis from the symmetric part
+        A = (R + np.eye(3)) / 2
+        ax = np.sqrt(np.clip(np.diag(A), 0, None))
+        i = int(np.argmax(ax))
+        ax = A[i] / ax[i]
+        return th * ax / np.linalg.norm(ax)
+    return th / (2 * np.sin(th)) * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+
+
+def _skew(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]], np.float64)
+
+
+def project(points_3d, pose, K):
+    """Projector.project_K (lib/utils/base_utils.py:289-294)."""
+    p = points_3d @ pose[:, :3].T + pose[:, 3:].T
+    p = p @ K.T
+    return p[:, :2] / p[:, 2:]
+
+
+def _dlt_pose(points_3d, points_2d, K):
+    """linear initial guess: DLT on normalised image points, projected onto SO(3)."""
+    n = points_3d.shape[0]
+    xn = (np.linalg.inv(K) @ np.concatenate([points_2d, np.ones((n, 1))], 1).T).T[:, :2]
+    c = points_3d.mean(0)
+    s = np.sqrt(((points_3d - c) ** 2).sum(1).mean()) + 1e-12
+    X = (points_3d - c) / s  # conditioning
+    A = np.zeros((2 * n, 12))
+    for i in range(n):
+        Xh = np.append(X[i], 1.0)
+        A[2 * i, 0:4] = Xh
+        A[2 * i, 8:12] = -xn[i, 0] * Xh
+        A[2 * i + 1, 4:8] = Xh
+        A[2 * i + 1, 8:12] = -xn[i, 1] * Xh
+    P = np.linalg.svd(A)[2][-1].reshape(3, 4)
+    if np.linalg.det(P[:, :3]) < 0:
+        P = -P
+    U, S, Vt = np.linalg.svd(P[:, :3])
+    R = U @ Vt
+    if np.linalg.det(R) < 0:
+        R = -R
+    t = P[:, 3] / S.mean()
+    t = t - R @ (c / s) * 1.0  # undo the centring ...
+    # ... X = (Xw - c)/s  =>  R X + t' = (R Xw)/s + (t' - R c/s)  => scale whole pose by s
+    return R, t * s
+
+
+def _residuals(x, points_3d, points_2d, K, W=None):
+    R = rodrigues(x[:3])
+    d = project(points_3d, np.concatenate([R, x[3:, None]], 1), K) - points_2d
+    if W is not None:  # uncertainty_pnp.cpp:29-30: r = W d with the symmetric 2x2 W = [[wxx,wxy],[wxy,wyy]]
+        d = np.stack([W[:, 0] * d[:, 0] + W[:, 1] * d[:, 1], W[:, 1] * d[:, 0] + W[:, 2] * d[:, 1]], 1)
+    return d.ravel()
+
+
+def pnp(points_3d, points_2d, camera_matrix, method="iterative", init=None):
+    """evaluation_utils.py:19-52  ->  [3,4] pose (R | t).  DLT initialisation + LM on the reprojection error."""
+    points_3d = np.ascontiguousarray(points_3d, np.float64)
+    points_2d = np.ascontiguousarray(points_2d, np.float64)
+    K = np.asarray(camera_matrix, np.float64)
+    assert points_3d.shape[0] == points_2d.shape[0], "points 3D and points 2D must have same number of vertices"
+    if init is None:
+        R0, t0 = _dlt_pose(points_3d, points_2d, K)  # det(R0) > 0 fixes the sign of the homogeneous solution
+        x0 = np.concatenate([rodrigues_inv(R0), t0])
+    else:
+        x0 = np.concatenate([rodrigues_inv(init[:, :3]), init[:, 3]])
+    sol = least_squares(_residuals, x0, args=(points_3d, points_2d, K), method="lm", xtol=1e-12, ftol=1e-12)
+    return np.concatenate([rodrigues(sol.x[:3]), sol.x[3:, None]], 1)
+
+
+def uncertainty_pnp(points_2d, weights_2d, points_3d, camera_matrix):
+    """extend_utils.py:63-114: weights_2d [pn,3] = (wxx, wxy, wyy); initialised from the 4 best-weighted points
+    (P3P there; the same 4-point LM fit here), refined by LM on the weighted residuals (uncertainty_pnp.cpp:61-92)."""
+    points_2d = np.asarray(points_2d, np.float64)
+    points_3d = np.asarray(points_3d, np.float64)
+    W = np.asarray(weights_2d, np.float64)
+    pose0 = pnp(points_3d, points_2d, camera_matrix)  # robust start (the reference's P3P start needs >= 4 good points)
+    x0 = np.concatenate([rodrigues_inv(pose0[:, :3]), pose0[:, 3]])
+    sol = least_squares(_residuals, x0, args=(points_3d, points_2d, np.asarray(camera_matrix, np.float64), W),
+                        method="lm", xtol=1e-12, ftol=1e-12)
+    return np.concatenate([rodrigues(sol.x[:3]), sol.x[3:, None]], 1)
+
+
+def uncertainty_pnp_v2(points_2d, covars, points_3d, camera_matrix):
+    """extend_utils.py:116-165: isotropic weight 1/lambda_max(cov) per key-point (0 when cov[0,0] < 1e-5)."""
+    covars = np.asarray(covars, np.float64)
+    w = np.array([0.0 if c[0, 0] < 1e-5 else 1.0 / np.max(np.linalg.eigvalsh(c)) for c in covars])
+    W = np.stack([w, np.zeros_like(w), w], 1)
+    return uncertainty_pnp(points_2d, W, points_3d, camera_matrix)
+
+
+# ---- metrics of Evaluator (evaluation_utils.py:75-134) -----------------------------------------------------
+def projection_2d_error(pose_pred, pose_target, model, K):
+    return float(np.mean(np.linalg.norm(project(model, pose_pred, K) - project(model, pose_target, K), axis=-1)))
+
+
+def add_error(pose_pred, pose_target, model):
+    a = model @ pose_pred[:, :3].T + pose_pred[:, 3]
+    b = model @ pose_target[:, :3].T + pose_target[:, 3]
+    return float(np.mean(np.linalg.norm(a - b, axis=-1)))
+
+
+def cm_degree_error(pose_pred, pose_target):
+    """(translation error in cm, rotation error in degrees) -- the 5cm5deg metric's two numbers (:126-134)."""
+    tr = np.linalg.norm(pose_pred[:, 3] - pose_target[:, 3]) * 100
+    c = min(np.trace(pose_pred[:, :3] @ pose_target[:, :3].T), 3.0)
+    return float(tr), float(np.rad2deg(np.arccos(np.clip((c - 1.) / 2., -1, 1))))

@@ -69,6 +69,11 @@ def load_library() -> C.CDLL:
     lib.pvnet_voting_for_hypothesis.restype = C.c_int
     lib.pvnet_voting_for_hypothesis.argtypes = [f32p, f32p, f32p, u8p, C.c_int, C.c_int, C.c_int, C.c_float,
                                                 C.c_void_p]
+    ws_tail = [C.c_int] * 6 + [C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.pvnet_vote_confidence.restype = C.c_int
+    lib.pvnet_vote_confidence.argtypes = [f32p, C.c_float, f32p] + ws_tail
+    lib.pvnet_vote_distribution.restype = C.c_int
+    lib.pvnet_vote_distribution.argtypes = [f32p, f32p] + ws_tail
     if lib.pvnet_vote_abi_version() != 1:
         raise RuntimeError("pvnet_amd: libpvnet_vote.so ABI version mismatch; rebuild it")
     _lib = lib
@@ -205,10 +210,79 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
         d = _debug_views(ws, L)
         d["status"] = status
         d["seed"] = seed
+        d["workspace"] = ws
         extras.append(d)
     if stage_times:
         extras.append(times)
     return (out, *extras) if extras else out
+
+
+def _ws_tail(L: Layout, max_num: int, ws: torch.Tensor):
+    return [L.b, L.h, L.w, L.vn, L.hn, max_num, C.c_void_p(ws.data_ptr()), C.c_size_t(L.total_bytes),
+            C.c_void_p(torch.cuda.current_stream(ws.device).cuda_stream)]
+
+
+def ransac_voting_layer_v5(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99, max_iter=20,
+                           min_num=5, max_num=100, *, conf_thresh=0.999, **kw):
+    """Drop-in for the reference's ``ransac_voting_layer_v5`` (ransac_voting_gpu.py:763-858): v3 plus a per-key-point
+    confidence = fraction of the (sub-sampled) foreground pixels voting for the refined point at 0.999 (:846-850).
+    :return: ([b,vn,2], [b,vn]) float32"""
+    max_num = int(min(max(int(max_num), 0), 2 ** 31 - 1))
+    out, dbg = ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh, confidence, max_iter, min_num,
+                                      max_num, return_debug=True, **kw)
+    L, ws = dbg["layout"], dbg["workspace"]
+    conf = torch.empty((L.b, L.vn), dtype=torch.float32, device=out.device)
+    with torch.cuda.device(out.device):
+        _check(load_library().pvnet_vote_confidence(C.c_void_p(out.data_ptr()), C.c_float(conf_thresh),
+                                                    C.c_void_p(conf.data_ptr()), *_ws_tail(L, max_num, ws)),
+               "pvnet_vote_confidence")
+    return out, conf
+
+
+def estimate_voting_distribution_with_mean(mask, vertex, mean, round_hyp_num=256, min_hyp_num=4096, topk=128,
+                                           inlier_thresh=0.99, min_num=5, max_num=30000, output_hyp=False, **kw):
+    """Drop-in for the reference's function of the same name (ransac_voting_gpu.py:333-406): ``min_hyp_num``
+    fresh hypotheses per key-point (the reference draws them in ceil(min_hyp_num/round_hyp_num) rounds of
+    independent pairs -- one draw of the same total here), their inlier ratios, and the ratio-weighted 2x2
+    covariance about ``mean`` [b,vn,2].  Returns ``(mean, cov [b,vn,2,2])``.  ``topk`` is unused upstream too.
+    (The reference selects ``mask == 1`` here rather than ``mask.byte() != 0``; identical for 0/1 masks.)"""
+    hn = -(-int(min_hyp_num) // int(round_hyp_num)) * int(round_hyp_num)
+    max_num = int(min(max(int(max_num), 0), 2 ** 31 - 1))
+    _, dbg = ransac_voting_layer_v3(mask, vertex, hn, inlier_thresh, min_num=min_num, max_num=max_num, refine=False,
+                                    return_debug=True, **kw)
+    L, ws = dbg["layout"], dbg["workspace"]
+    mean_c = mean.to(device=ws.device, dtype=torch.float32).contiguous()
+    cov = torch.empty((L.b, L.vn, 2, 2), dtype=torch.float32, device=ws.device)
+    with torch.cuda.device(ws.device):
+        _check(load_library().pvnet_vote_distribution(C.c_void_p(mean_c.data_ptr()), C.c_void_p(cov.data_ptr()),
+                                                      *_ws_tail(L, max_num, ws)), "pvnet_vote_distribution")
+    if output_hyp:
+        return mean, cov, dbg["hyp"].permute(0, 2, 1, 3), dbg["counts"].permute(0, 2, 1)
+    return mean, cov
+
+
+def generate_hypothesis_counts(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99, max_iter=20,
+                               min_num=5, max_num=30000, **kw):
+    """The reference's Python-level ``generate_hypothesis`` (ransac_voting_gpu.py:983-1034, used by the hypothesis
+    visualiser of tools/demo.py:120-134): all hypotheses and their inlier counts.
+    :return: ([b,hn,vn,2] float32, [b,hn,vn] int64)   (skipped images: zeros)"""
+    _, dbg = ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh, min_num=min_num, max_num=max_num,
+                                    refine=False, return_debug=True, **kw)
+    return dbg["hyp"].permute(0, 2, 1, 3).contiguous(), dbg["counts"].permute(0, 2, 1).contiguous().long()
+
+
+def ransac_motion_voting(mask, vertex):
+    """ransac_voting_gpu.py:960-981: per image, the mean over foreground pixels of (vertex + pixel coordinate).
+    Off the hot path and device-agnostic upstream as well: plain torch, vectorised over the batch."""
+    b, h, w, vn, _ = vertex.shape
+    fg = (mask.to(torch.uint8) if mask.dtype != torch.bool else mask).ne(0)
+    ys, xs = torch.meshgrid(torch.arange(h, device=vertex.device, dtype=torch.float32),
+                            torch.arange(w, device=vertex.device, dtype=torch.float32), indexing="ij")
+    coords = torch.stack([xs, ys], -1)[None, :, :, None, :]  # (x, y) = (col, row)
+    wgt = fg[..., None, None].to(torch.float32)
+    cnt = wgt.sum(dim=(1, 2)).clamp_min(1.0)
+    out = ((vertex.float() + coords) * wgt).sum(dim=(1, 2)) / cnt
+    return torch.where(fg.flatten(1).any(1)[:, None, None], out, torch.zeros_like(out))
 
 
 # ---------------------------------------------------------------------------------------------------------

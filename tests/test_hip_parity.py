@@ -307,3 +307,58 @@ def test_sharded_calls_reproduce_the_whole_batch():
     assert torch.equal(whole, torch.cat([lo, hi]))
     wrong = voting.ransac_voting_layer_v3(m[2:], v[2:], 64, inlier_thresh=0.99, seed=8, image_offset=0)
     assert not torch.equal(whole[2:], wrong)
+
+
+# ------------------------------------------------------------------------------------------------ SURVEY 8(f) rows
+def test_v5_confidence_matches_oracle():
+    mask, planar, _, vnp = small_batch(b=2, first=600, h=120, w=160, radius=20)
+    m, v = to_dev(mask, planar)
+    pts, conf = voting.ransac_voting_layer_v5(m, v, 128, inlier_thresh=0.99, max_num=100, seed=6, literal=True)
+    ref, rdbg = O.ransac_voting_layer_v3(mask, vnp, 128, inlier_thresh=0.99, max_num=100, seed=6, dtype=np.float32,
+                                         return_debug=True)
+    assert np.abs(pts.cpu().numpy() - ref).max() < 1e-4
+    for bi, d in enumerate(rdbg):  # ransac_voting_gpu.py:846-850 on the sub-sampled pixel list
+        c = O.voting_counts(d["direct"], d["coords"], pts[bi].cpu().numpy()[None], 0.999, np.float32)[0]
+        np.testing.assert_allclose(conf[bi].cpu().numpy(), c.astype(np.float32) / np.float32(d["tn"]), atol=1e-6)
+
+
+def test_generate_hypothesis_counts_and_distribution():
+    mask, planar, kpts, vnp = small_batch(b=2, first=610, h=120, w=160, radius=20)
+    mask[1] = 0  # a skipped image
+    m, v = to_dev(mask, planar)
+    hyp, cnt = voting.generate_hypothesis_counts(m, v, 256, inlier_thresh=0.99, seed=4, literal=True)
+    _, rdbg = O.ransac_voting_layer_v3(mask, vnp, 256, inlier_thresh=0.99, seed=4, dtype=np.float32,
+                                       return_debug=True)
+    assert hyp.shape == (2, 256, 9, 2) and cnt.shape == (2, 256, 9) and cnt.dtype == torch.int64
+    assert hyp[0].cpu().numpy().tobytes() == rdbg[0]["hyp"].astype(np.float32).tobytes()
+    np.testing.assert_array_equal(cnt[0].cpu().numpy(), rdbg[0]["counts"])
+    assert (cnt[1] == 0).all() and (hyp[1] == 0).all()
+    mean = torch.from_numpy(kpts.astype(np.float32)).to(dev())
+    mean_out, cov = voting.estimate_voting_distribution_with_mean(m, v, mean, round_hyp_num=64, min_hyp_num=256,
+                                                                  inlier_thresh=0.99, seed=4, literal=True)
+    assert mean_out is mean and cov.shape == (2, 9, 2, 2)
+    ref = O.estimate_voting_distribution_with_mean(mask, vnp, kpts.astype(np.float32), 256, 0.99, seed=4,
+                                                   dtype=np.float32)
+    np.testing.assert_allclose(cov.cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_motion_voting_matches_oracle():
+    mask, planar, _, vnp = small_batch(b=3, first=620, h=64, w=80, radius=9)
+    mask[2] = 0
+    m, v = to_dev(mask, planar)
+    out = voting.ransac_motion_voting(m, v).cpu().numpy()
+    np.testing.assert_allclose(out, O.ransac_motion_voting(mask, vnp), rtol=1e-5, atol=1e-3)
+
+
+def test_demo_fixture_end_to_end_pose(demo_fixture):
+    """BASELINE.json config 2 without the (absent) backbone weights: ground-truth field of the demo image ->
+    HIP voting -> host PnP -> the fixture's pose (tools/demo.py:166-179)."""
+    from pvnet_amd import pnp as P
+    f = demo_fixture
+    planar = synth.field_from_keypoints(f["mask"].astype(bool), f["points_2d"])
+    m, v = to_dev(f["mask"][None].astype(np.int64), planar[None])
+    kpts = voting.ransac_voting_layer_v3(m, v, 512, inlier_thresh=0.99)[0].cpu().numpy()  # demo.py:55
+    pose = P.pnp(f["points_3d"], kpts, f["K"])
+    tr_cm, rot_deg = P.cm_degree_error(pose, f["pose"].astype(np.float64))
+    assert tr_cm < 0.05 and rot_deg < 0.1
+    assert P.projection_2d_error(pose, f["pose"].astype(np.float64), f["bb8_3d"], f["K"]) < 0.01
