@@ -996,6 +996,7 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     // a scoring workgroup (4 waves) covers wg_g hypothesis groups x wg_s chunks of one (image, key-point)
     const int wg_g = hgroups >= 3 ? 4 : hgroups;
     hgroups = (hgroups + wg_g - 1) / wg_g * wg_g;
+
     const long long units = (long long)b * vn * hgroups;
     int chunk = units >= 512 ? 256 : (units >= 128 ? 128 : 64);
     chunk = env_int("PVNET_SCORE_CHUNK", chunk);
@@ -1010,6 +1011,7 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     L->hn_pad = hgroups * 64 * hpl;
     L->wg_g = wg_g;
     L->wg_s = 4 / wg_g;
+    L->reserved_ = 0;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     L->nseg = (L->words + SEG_WORDS - 1) / SEG_WORDS;

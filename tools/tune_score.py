@@ -29,8 +29,8 @@ def run(n=10, **kw):
 
 
 configs = []
-for kg, hpl, chunk in itertools.product([1, 3, 9], [4], [256]):
-    configs.append(dict(PVNET_COMPACT_KG=kg, PVNET_SCORE_HPL=hpl, PVNET_SCORE_CHUNK=chunk))
+for wgs, hpl, chunk in itertools.product([8], [4, 8], [128, 256]):
+    configs.append(dict(PVNET_SCORE_WGS_PER_CU=wgs, PVNET_SCORE_HPL=hpl, PVNET_SCORE_CHUNK=chunk))
 for extra in sys.argv[1:]:
     configs.append(dict(kv.split("=") for kv in extra.split(",")))
 for c in configs:
