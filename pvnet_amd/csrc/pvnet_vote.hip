@@ -45,7 +45,11 @@ constexpr int CTRL_STRIDE = 8;
 enum { C_TN0 = 0, C_TN = 1, C_STATUS = 2, C_ITEM_BASE = 3, C_NCHUNKS = 4, C_OX = 5, C_OY = 6 };
 
 constexpr int SEG_WORDS = 64;          // a segment = 64 words = 4096 pixels: the unit of K1 / K1b / K2 workgroups
-constexpr int K1_WORDS_PER_WAVE = SEG_WORDS / 4;  // 16 independent loads in flight per lane
+constexpr int K1_WAVES = 16;            // waves per K1 workgroup (one workgroup = one segment): measured 4 -> 22.5 us,
+                                        // 8 -> 20.6 us, 16 -> 19.4 us for the 78.6 MB int64 masks of a batch of 32
+constexpr int K1B_WAVES = 4;            // K1b (usually a no-op): small workgroups
+constexpr int K1B_WORDS_PER_WAVE = SEG_WORDS / K1B_WAVES;
+constexpr int K1_WORDS_PER_WAVE = SEG_WORDS / K1_WAVES;  // independent loads in flight per lane
 constexpr int K2_WORDS_PER_BLOCK = SEG_WORDS;
 constexpr int PAD = 8;                 // scoring consumes records 8 at a time; tails are padded with sentinels
 
@@ -183,10 +187,10 @@ __device__ __forceinline__ bool load_fg(const void* m, int64_t off) {
 }
 
 template <int DT>
-__global__ __launch_bounds__(256) void mask_bits_kernel(VoteParams P) {
+__global__ __launch_bounds__(64 * K1_WAVES) void mask_bits_kernel(VoteParams P) {
     const int bi = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int word0 = (blockIdx.x * 4 + wave) * K1_WORDS_PER_WAVE;
+    const int word0 = (blockIdx.x * K1_WAVES + wave) * K1_WORDS_PER_WAVE;
     bool f[K1_WORDS_PER_WAVE];
 #pragma unroll
     for (int i = 0; i < K1_WORDS_PER_WAVE; ++i) {
@@ -211,11 +215,12 @@ __global__ __launch_bounds__(256) void mask_bits_kernel(VoteParams P) {
         if (lane == 0 && word0 + i < P.words) P.bits[(size_t)bi * P.words + word0 + i] = m;
         cnt += __popcll(m);
     }
-    __shared__ int s_cnt[4];
+    __shared__ int s_cnt[K1_WAVES];
     if (lane == 0) s_cnt[wave] = cnt;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        int t = 0;
+        for (int i = 0; i < K1_WAVES; ++i) t += s_cnt[i];
         P.seg[bi * P.nseg + blockIdx.x] = t;   // foreground pixels of this 4096-pixel segment (thinned by K1b)
         P.seg0[bi * P.nseg + blockIdx.x] = t;  // ... as the mask has them (tn0 = their sum)
     }
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256) void mask_bits_kernel(VoteParams P) {
 // ------------------------------------------------------------------------------------------------------------
 // K1b: Bernoulli subsample when tn0 > max_num                 (ransac_voting_gpu.py:537-540)
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void subsample_kernel(VoteParams P) {
+__global__ __launch_bounds__(64 * K1B_WAVES) void subsample_kernel(VoteParams P) {
     const int bi = blockIdx.y;
     // tn0 = sum of this image's segment counts; every wave reduces it for itself (no barrier, no atomics).
     // The counts this launch reads are K1's; blocks of this launch overwrite only their OWN segment's count,
@@ -240,9 +245,9 @@ __global__ __launch_bounds__(256) void subsample_kernel(VoteParams P) {
     const uint32_t thr = (uint32_t)t;
     const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_SUB, (uint32_t)(P.image_base + bi));
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int word0 = (blockIdx.x * 4 + wave) * K1_WORDS_PER_WAVE;
+    const int word0 = (blockIdx.x * K1B_WAVES + wave) * K1B_WORDS_PER_WAVE;
     int cnt = 0;
-    for (int i = 0; i < K1_WORDS_PER_WAVE; ++i) {
+    for (int i = 0; i < K1B_WORDS_PER_WAVE; ++i) {
         const int j = word0 + i;
         if (j >= P.words) break;
         const unsigned long long word = P.bits[(size_t)bi * P.words + j];
@@ -252,10 +257,14 @@ __global__ __launch_bounds__(256) void subsample_kernel(VoteParams P) {
         if (lane == 0) P.bits[(size_t)bi * P.words + j] = m;
         cnt += __popcll(m);
     }
-    __shared__ int s_cnt[4];
+    __shared__ int s_cnt[K1B_WAVES];
     if (lane == 0) s_cnt[wave] = cnt;
     __syncthreads();
-    if (threadIdx.x == 0) P.seg[bi * P.nseg + blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int i = 0; i < K1B_WAVES; ++i) t += s_cnt[i];
+        P.seg[bi * P.nseg + blockIdx.x] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -874,17 +883,17 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
     {   // K1
         dim3 grid(P.nseg, P.b);
         switch (P.mask_dtype) {
-            case PVNET_MASK_U8: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_U8>, grid, dim3(256), 0, s, P); break;
-            case PVNET_MASK_I16: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I16>, grid, dim3(256), 0, s, P); break;
-            case PVNET_MASK_I32: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I32>, grid, dim3(256), 0, s, P); break;
-            case PVNET_MASK_I64: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I64>, grid, dim3(256), 0, s, P); break;
-            case PVNET_MASK_F32: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_F32>, grid, dim3(256), 0, s, P); break;
+            case PVNET_MASK_U8: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_U8>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
+            case PVNET_MASK_I16: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I16>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
+            case PVNET_MASK_I32: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I32>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
+            case PVNET_MASK_I64: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I64>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
+            case PVNET_MASK_F32: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_F32>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
             default: return PVNET_E_BADARG;
         }
         PV_LAUNCH_CHECK();
         PV_HIP(mark(1));
         if (P.max_num < P.npix) {  // host-known: subsampling can only trigger when max_num < h*w
-            hipLaunchKernelGGL(subsample_kernel, grid, dim3(256), 0, s, P);
+            hipLaunchKernelGGL(subsample_kernel, grid, dim3(64 * K1B_WAVES), 0, s, P);
             PV_LAUNCH_CHECK();
         }
         PV_HIP(mark(2));
@@ -989,7 +998,7 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
         cap = c < npix ? c : npix;
     }
     cap = (cap + PAD - 1) / PAD * PAD + PAD;
-    int hpl = hn >= 512 ? 4 : (hn >= 128 ? 2 : 1);
+    int hpl = hn >= 768 ? 8 : (hn >= 384 ? 4 : (hn >= 128 ? 2 : 1));  // tuned at hn = 1024 (profiles/r01_tune13)
     hpl = env_int("PVNET_SCORE_HPL", hpl);
     if (hpl != 1 && hpl != 2 && hpl != 4 && hpl != 8) return PVNET_E_UNSUPPORTED;
     int hgroups = (hn + 64 * hpl - 1) / (64 * hpl);
@@ -998,7 +1007,7 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     hgroups = (hgroups + wg_g - 1) / wg_g * wg_g;
 
     const long long units = (long long)b * vn * hgroups;
-    int chunk = units >= 512 ? 256 : (units >= 128 ? 128 : 64);
+    int chunk = units >= 128 ? 128 : 64;
     chunk = env_int("PVNET_SCORE_CHUNK", chunk);
     if (chunk < PAD || chunk % PAD != 0 || chunk > 1024) return PVNET_E_UNSUPPORTED;  // LDS: 4 * 1024 * 32 B
     L->b = b; L->h = h; L->w = w; L->vn = vn; L->hn = hn;

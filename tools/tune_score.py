@@ -29,13 +29,21 @@ def run(n=10, **kw):
 
 
 configs = []
-for wgs, hpl, chunk in itertools.product([8], [4, 8], [128, 256]):
+for wgs, hpl, chunk in itertools.product([6, 8], [4, 8], [128, 256]):
     configs.append(dict(PVNET_SCORE_WGS_PER_CU=wgs, PVNET_SCORE_HPL=hpl, PVNET_SCORE_CHUNK=chunk))
 for extra in sys.argv[1:]:
     configs.append(dict(kv.split("=") for kv in extra.split(",")))
-for c in configs:
-    for k, x in c.items():
-        os.environ[k] = str(x)
-    t = run()
-    print(" ".join(f"{k[12:]}={x}" for k, x in c.items()), "| score %.1f us | total %.1f us |" % (t["score"] * 1e3, sum(t.values()) * 1e3),
-          " ".join(f"{k}={x * 1e3:.1f}" for k, x in t.items() if k != "score"), flush=True)
+ROUNDS = int(os.environ.get("TUNE_ROUNDS", 3))
+res = {}
+for rnd in range(ROUNDS):  # interleaved rounds: run-to-run drift is a few percent on this part
+    for i, c in enumerate(configs):
+        for k, x in c.items():
+            os.environ[k] = str(x)
+        res.setdefault(i, []).append(run())
+for i, c in enumerate(configs):
+    ts = res[i]
+    med = {k: float(np.median([t[k] for t in ts])) for k in ts[0]}
+    tot = sorted(sum(t.values()) for t in ts)
+    print(" ".join(f"{k[6:]}={x}" for k, x in c.items()), "| score med %.1f min %.1f us | total med %.1f min %.1f us |" %
+          (med["score"] * 1e3, min(t["score"] for t in ts) * 1e3, tot[len(tot) // 2] * 1e3, tot[0] * 1e3),
+          " ".join(f"{k}={x * 1e3:.1f}" for k, x in med.items() if k != "score"), flush=True)
