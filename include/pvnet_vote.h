@@ -73,7 +73,8 @@ typedef struct PvnetVoteLayout {
     size_t off_partial;     /* uint16 [b][vn][max_chunks][hn_pad]  per-chunk inlier counts                  */
     size_t off_counts;      /* int32  [b][vn][hn_pad]      inlier count of every hypothesis                 */
     size_t off_win;         /* int32  [b][vn][2]           (winner index, winner count)                     */
-    size_t off_seg;         /* int32  [b][nseg]            foreground count of every 4096-pixel segment     */
+    size_t off_seg;         /* int32  [2][b][nseg]         foreground count of every 4096-pixel segment     */
+    size_t off_items;       /* int32x4 [max items]         scoring work items (image, kp, chunk group, slice) */
     size_t total_bytes;
     int32_t nseg;           /* ceil(words / 64)                                                             */
     int32_t wg_g, wg_s;     /* a scoring workgroup covers wg_g hypothesis groups x wg_s chunks (wg_g*wg_s=4) */
@@ -112,11 +113,10 @@ int pvnet_vote_v3(const void* mask, int mask_dtype, const int64_t mask_strides[3
 #define PVNET_STAGE_MASK      0   /* mask -> bit mask + foreground count          (HBM read of the mask)     */
 #define PVNET_STAGE_SUBSAMPLE 1   /* Bernoulli subsample when tn0 > max_num                                  */
 #define PVNET_STAGE_COMPACT   2   /* order-preserving compaction + vector gather  (HBM read of fg vectors)   */
-#define PVNET_STAGE_PLAN      3   /* work-item prefix                                                        */
-#define PVNET_STAGE_HYP       4   /* hypothesis generation                                                   */
-#define PVNET_STAGE_SCORE     5   /* inlier scoring (dominant, fp32 VALU)                                    */
-#define PVNET_STAGE_REFINE    6   /* arg-max + least-squares refinement                                      */
-#define PVNET_NUM_STAGES      7
+#define PVNET_STAGE_HYP       3   /* hypothesis generation + per-image work-item plan                        */
+#define PVNET_STAGE_SCORE     4   /* inlier scoring (dominant, fp32 VALU)                                    */
+#define PVNET_STAGE_REFINE    5   /* arg-max + least-squares refinement                                      */
+#define PVNET_NUM_STAGES      6
 int pvnet_vote_v3_profiled(const void* mask, int mask_dtype, const int64_t mask_strides[3],
                            const float* vertex, const int64_t vertex_strides[5],
                            int b, int h, int w, int vn, int hn,

@@ -67,6 +67,7 @@ struct VoteParams {
     const int32_t* idxs;
     uint32_t flags;
     int32_t* ctrl;
+    int4* items;
     int32_t* seg;
     int32_t* seg0;
     int nseg;
@@ -397,50 +398,52 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// plan (runs in block (0,0) of the hypothesis launch): chunk counts + exclusive prefix of scoring work items
+// plan (one extra block per image in the hypothesis launch): the image's gates (ransac_voting_gpu.py:531-534),
+// chunk count, local origin, its offset in the list of scoring work items (each block sums the item counts of the
+// images before it -- b loads, no serial scan) and one 16-byte descriptor per work item.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void plan_items(const VoteParams& P) {
-    __shared__ int s_scan[256];
-    __shared__ int s_running;
-    if (threadIdx.x == 0) s_running = 0;
+__device__ __forceinline__ int plan_item_count(const VoteParams& P, int j, int* nch_out) {
+    const int tn0 = P.ctrl[j * CTRL_STRIDE + C_TN0], tn = P.ctrl[j * CTRL_STRIDE + C_TN];
+    const bool skip = tn0 < P.min_num || tn <= 0;
+    const int nch = skip ? 0 : (tn + P.chunk - 1) / P.chunk;
+    if (nch_out) *nch_out = nch;
+    return ((nch + P.wg_s - 1) / P.wg_s) * P.vn * (P.hgroups / P.wg_g);
+}
+
+__device__ __forceinline__ void plan_image(const VoteParams& P, int bi) {
+    __shared__ int s_part[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int part = 0;
+    for (int j = threadIdx.x; j < bi; j += 256) part += plan_item_count(P, j, nullptr);
+    part = wave_reduce_add(part);
+    if (lane == 0) s_part[wave] = part;
     __syncthreads();
-    for (int base = 0; base < P.b; base += 256) {
-        const int i = base + threadIdx.x;
-        int n = 0;
-        if (i < P.b) {
-            const int tn0 = P.ctrl[i * CTRL_STRIDE + C_TN0];
-            const int tn = P.ctrl[i * CTRL_STRIDE + C_TN];
-            const bool skip = tn0 < P.min_num || tn <= 0;
-            const int nch = skip ? 0 : (tn + P.chunk - 1) / P.chunk;
-            P.ctrl[i * CTRL_STRIDE + C_NCHUNKS] = nch;
-            const int pm = skip ? 0 : P.pix[(size_t)i * P.cap + tn / 2];  // local origin for the expanded form
-            P.ctrl[i * CTRL_STRIDE + C_OX] = pm % P.w;
-            P.ctrl[i * CTRL_STRIDE + C_OY] = pm / P.w;
-            if (skip) P.ctrl[i * CTRL_STRIDE + C_STATUS] |= PVNET_S_SKIPPED;
-            n = ((nch + P.wg_s - 1) / P.wg_s) * P.vn * (P.hgroups / P.wg_g);  // workgroup items
-        }
-        s_scan[threadIdx.x] = n;
-        __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {
-            const int t = threadIdx.x >= o ? s_scan[threadIdx.x - o] : 0;
-            __syncthreads();
-            s_scan[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < P.b) P.ctrl[i * CTRL_STRIDE + C_ITEM_BASE] = s_running + s_scan[threadIdx.x] - n;
-        __syncthreads();
-        if (threadIdx.x == 255) s_running += s_scan[255];
-        __syncthreads();
+    const int base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    int nch;
+    const int n = plan_item_count(P, bi, &nch);
+    if (threadIdx.x == 0) {
+        const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
+        P.ctrl[bi * CTRL_STRIDE + C_NCHUNKS] = nch;
+        P.ctrl[bi * CTRL_STRIDE + C_ITEM_BASE] = base;
+        const int pm = nch ? P.pix[(size_t)bi * P.cap + tn / 2] : 0;  // local origin for the expanded form
+        P.ctrl[bi * CTRL_STRIDE + C_OX] = pm % P.w;
+        P.ctrl[bi * CTRL_STRIDE + C_OY] = pm / P.w;
+        if (!nch) P.ctrl[bi * CTRL_STRIDE + C_STATUS] |= PVNET_S_SKIPPED;
+        if (bi == P.b - 1) P.ctrl[P.b * CTRL_STRIDE] = base + n;  // total number of work items
     }
-    if (threadIdx.x == 0) P.ctrl[P.b * CTRL_STRIDE] = s_running;
+    const int HQ = P.hgroups / P.wg_g, nchg = (nch + P.wg_s - 1) / P.wg_s;
+    for (int local = threadIdx.x; local < n; local += 256) {
+        const int hq = local % HQ, t = local / HQ;
+        P.items[base + local] = make_int4(bi, t / nchg, t % nchg, hq);  // (image, key-point, chunk group, hyp slice)
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // K3: hypotheses                                               (ransac_voting_gpu.py:547,554; kernel.cu:11-49)
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
-    if (blockIdx.x == gridDim.x - 1) {  // one extra block per image row; the first of them plans the work items
-        if (blockIdx.y == 0) plan_items(P);  // consumed by the next launches only
+    if (blockIdx.x == gridDim.x - 1) {  // one extra block per image plans its scoring work items
+        plan_image(P, blockIdx.y);      // (consumed by the next launches only)
         return;
     }
     const int bi = blockIdx.y;
@@ -500,23 +503,12 @@ __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int32_t* __restrict__ ctrl = P.ctrl;
     const int total = ctrl[P.b * CTRL_STRIDE];
-    const int HQ = P.hgroups / G;
 
     for (int item = blockIdx.x; item < total; item += gridDim.x) {
-        int lo = 0, hi = P.b - 1;  // image owning this item: last bi with item_base[bi] <= item
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (ctrl[mid * CTRL_STRIDE + C_ITEM_BASE] <= item) lo = mid; else hi = mid - 1;
-        }
-        const int bi = lo;
-        const int local = item - ctrl[bi * CTRL_STRIDE + C_ITEM_BASE];
+        const int4 desc = P.items[item];  // (image, key-point, chunk group, hypothesis slice), planned by K3
+        const int bi = desc.x, k = desc.y, cg = desc.z, hq = desc.w;
         const int nch = ctrl[bi * CTRL_STRIDE + C_NCHUNKS];
         const int tn = ctrl[bi * CTRL_STRIDE + C_TN];
-        const int nchg = (nch + S - 1) / S;
-        const int hq = local % HQ;
-        const int t = local / HQ;
-        const int cg = t % nchg;
-        const int k = t / nchg;
         const size_t bk = (size_t)bi * P.vn + k;
         const int tpad = (tn + PAD - 1) / PAD * PAD;  // records up to tpad exist (sentinels past tn)
 
@@ -908,12 +900,11 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
         PV_LAUNCH_CHECK();
         PV_HIP(mark(3));
     }
-    PV_HIP(mark(4));  // (the work-item plan is computed by block (0,0) of the hypothesis launch)
     {   // K3
         dim3 grid((P.hn * P.vn + 255) / 256 + 1, P.b);
         hipLaunchKernelGGL(hypothesis_kernel, grid, dim3(256), 0, s, P);
         PV_LAUNCH_CHECK();
-        PV_HIP(mark(5));
+        PV_HIP(mark(4));
     }
     {   // K4: persistent grid, work items strided over its waves
         const long long max_items =
@@ -925,14 +916,14 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
         int rc = literal ? launch_score<true>(P, dim3((unsigned)wgs), s) : launch_score<false>(P, dim3((unsigned)wgs), s);
         if (rc) return rc;
         PV_LAUNCH_CHECK();
-        PV_HIP(mark(6));
+        PV_HIP(mark(5));
     }
     {   // K5
         dim3 grid(P.vn, P.b);
         if (literal) hipLaunchKernelGGL(select_refine_kernel<true>, grid, dim3(RT), 0, s, P);
         else hipLaunchKernelGGL(select_refine_kernel<false>, grid, dim3(RT), 0, s, P);
         PV_LAUNCH_CHECK();
-        PV_HIP(mark(7));
+        PV_HIP(mark(6));
     }
     return 0;
 }
@@ -962,6 +953,7 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     P.tau = (thresh > 0.f && thresh < 1.f) ? (float)(sqrt(1.0 - (double)thresh * thresh) / (double)thresh) : 0.f;
     P.min_num = min_num; P.max_num = max_num; P.seed = seed; P.image_base = image_base; P.idxs = idxs; P.flags = flags;
     P.ctrl = reinterpret_cast<int32_t*>(base + L.off_ctrl);
+    P.items = reinterpret_cast<int4*>(base + L.off_items);
     P.seg = reinterpret_cast<int32_t*>(base + L.off_seg);
     P.seg0 = P.seg + (size_t)L.b * L.nseg;
     P.nseg = L.nseg;
@@ -1026,6 +1018,8 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     L->nseg = (L->words + SEG_WORDS - 1) / SEG_WORDS;
     L->off_ctrl = take(sizeof(int32_t) * CTRL_STRIDE * (size_t)(b + 1));
     L->off_seg = take(sizeof(int32_t) * 2 * (size_t)b * L->nseg);  // thinned counts, then the mask's own
+    L->off_items = take(sizeof(int32_t) * 4 * (size_t)b * vn * (hgroups / wg_g) *
+                        (size_t)((L->max_chunks + L->wg_s - 1) / L->wg_s));
     L->off_bits = take(sizeof(uint64_t) * (size_t)b * L->words);
     L->off_pix = take(sizeof(int32_t) * (size_t)b * cap);
     L->off_rec = take(sizeof(float) * 4 * (size_t)b * vn * cap);

@@ -26,8 +26,8 @@ LIB_PATH = os.path.join(_HERE, "libpvnet_vote.so")
 F_LITERAL = 1
 F_NO_REFINE = 2
 S_SKIPPED, S_SINGULAR, S_NO_INLIER, S_OVERFLOW = 1, 2, 4, 8
-NUM_STAGES = 7
-STAGE_NAMES = ("mask_bits", "subsample", "compact", "plan", "hypotheses", "score", "select_refine")
+NUM_STAGES = 6
+STAGE_NAMES = ("mask_bits", "subsample", "compact", "hypotheses", "score", "select_refine")
 
 
 class Layout(C.Structure):
@@ -35,7 +35,7 @@ class Layout(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("b", "h", "w", "vn", "hn", "cap", "words", "chunk", "max_chunks", "hpl",
                                           "hgroups", "hn_pad")] + \
                [(n, C.c_size_t) for n in ("off_ctrl", "off_bits", "off_pix", "off_rec", "off_tq", "off_dir", "off_hyp",
-                                          "off_partial", "off_counts", "off_win", "off_seg", "total_bytes")] + \
+                                          "off_partial", "off_counts", "off_win", "off_seg", "off_items", "total_bytes")] + \
                [("nseg", C.c_int32), ("wg_g", C.c_int32), ("wg_s", C.c_int32), ("reserved_", C.c_int32)]
 
 
