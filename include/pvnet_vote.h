@@ -66,9 +66,8 @@ typedef struct PvnetVoteLayout {
     size_t off_ctrl;        /* int32 [b][8]: tn0, tn, status, item_base, nchunks, -, -, -  ; then [8] global */
     size_t off_bits;        /* uint64 [b][words]           foreground (after subsampling) bit mask          */
     size_t off_pix;         /* int32  [b][cap]             linear pixel index y*w+x of compacted pixel t    */
-    size_t off_rec;         /* float4 [b][vn][cap]         scoring record (x, y, My, -Mx), M = 2^90 * direction     */
-    size_t off_tq;          /* float2 [b][vn][cap]         (Tx, Ty) = tan(acos(thresh)) * M                         */
-    size_t off_dir;         /* float2 [b][vn][cap]         raw direction (ux, uy)                           */
+    size_t off_rec;         /* float4 [b][vn][cap]         record (x, y, My, -Mx), M = 2^90 * direction (exact scaling;
+                                                           literal mode: (x, y, ux, uy)) -- the only per-pixel data */
     size_t off_hyp;         /* float2 [b][vn][hn_pad]      hypotheses                                       */
     size_t off_partial;     /* uint16 [b][vn][max_chunks][hn_pad]  per-chunk inlier counts                  */
     size_t off_counts;      /* int32  [b][vn][hn_pad]      inlier count of every hypothesis                 */
@@ -129,9 +128,10 @@ int pvnet_vote_v3_profiled(const void* mask, int mask_dtype, const int64_t mask_
  * the same (b,h,w,vn,hn,max_num) on the same stream (they read its compacted pixel lists, hypotheses and counts).
  *
  * pvnet_vote_confidence: ransac_voting_layer_v5's second output (ransac_voting_gpu.py:846-850): out_conf[b,vn] =
- *   fraction of the image's kept pixels whose direction points at kpts[b,vn,2] within `thresh` (0.999 there). */
-int pvnet_vote_confidence(const float* kpts, float thresh, float* out_conf, int b, int h, int w, int vn, int hn,
-                          int max_num, void* workspace, size_t workspace_bytes, void* stream);
+ *   fraction of the image's kept pixels whose direction points at kpts[b,vn,2] within `thresh` (0.999 there).
+ *   vote_flags = the flags of that pvnet_vote_v3 call (its PVNET_F_LITERAL bit decides the record format). */
+int pvnet_vote_confidence(const float* kpts, float thresh, float* out_conf, uint32_t vote_flags, int b, int h, int w,
+                          int vn, int hn, int max_num, void* workspace, size_t workspace_bytes, void* stream);
 /* pvnet_vote_distribution: estimate_voting_distribution_with_mean's epilogue (ransac_voting_gpu.py:389-404):
  *   out_cov[b,vn,2,2] = sum_h w_h (hyp_h - mean)(hyp_h - mean)^T / (sum_h w_h + 1e-3), w_h = inlier ratio of
  *   hypothesis h where it is within 0.1 of the key-point's best ratio, else 0; mean [b,vn,2]. */

@@ -74,8 +74,6 @@ struct VoteParams {
     uint64_t* bits;
     int32_t* pix;
     float4* rec;
-    float2* tq;
-    float2* dir;
     float2* hyp;
     uint16_t* partial;
     int32_t* counts;
@@ -126,6 +124,14 @@ __device__ __forceinline__ bool inlier_literal(float cx, float cy, float nx, flo
 // Zero directions (|u| < 1e-6, kernel.cu:121) are stored as zero records and never vote; a hypothesis that sits
 // exactly on a pixel gives s = 0 and does not vote either, as in the reference.
 constexpr float kVoteScale = 0x1p90f;
+constexpr float kVoteUnscale = 0x1p-90f;
+// raw direction of a record: fast records hold (x, y, My, -Mx) with M = 2^90 * u (an exact power-of-two scaling, so
+// u comes back bit for bit; directions below 1e-6 were stored as zero and count as zero everywhere); literal
+// records hold (x, y, ux, uy) themselves.
+template <bool LITERAL>
+__device__ __forceinline__ float2 rec_dir(float4 q) {
+    return LITERAL ? make_float2(q.z, q.w) : make_float2(-q.w * kVoteUnscale, q.z * kVoteUnscale);
+}
 __device__ __forceinline__ float vote_fast(float cx, float cy, float My, float nMx, float Tx, float Ty, float hx,
                                            float hy) {
     const float dx = hx - cx, dy = hy - cy;
@@ -141,9 +147,10 @@ __device__ __forceinline__ float vote_fast(float cx, float cy, float My, float n
 // measured against float64 arithmetic on the benchmark data (tools/precision_study.py) this form flips 3e-8 of the
 // pair tests, vote_fast 1e-8, and the reference's own float32 sqrt/divide order 6e-7.
 // per-pixel constants as staged in LDS: a = (My, -Mx, -Ec, Tx) [ds_read_b128], b = (Ty, -Ed) [ds_read_b64]
-__device__ __forceinline__ void make_pixrec(float4 q, float2 tq, float ox, float oy, float4& a, float2& b) {
+__device__ __forceinline__ void make_pixrec(float4 q, float tau, float ox, float oy, float4& a, float2& b) {
     const float cx = q.x - ox, cy = q.y - oy;  // exact: integer pixel coordinates
     const float My = q.z, nMx = q.w;
+    const float2 tq = make_float2(tau * -nMx, tau * My);  // T = tan(acos(thresh)) * M
     const float Ec = fmaf(cy, nMx, cx * My);
     const float Ed = fmaf(cy, tq.y, cx * tq.x);
     a = make_float4(My, nMx, -Ec, tq.x);
@@ -334,7 +341,6 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
         for (int kk = 0; kk < K2_KG; ++kk) {
             if (k0 + kk >= P.vn) break;
             const size_t o = ((size_t)bi * P.vn + k0 + kk) * P.cap + pos;
-            P.dir[o] = make_float2(ux[kk], uy[kk]);
             if (LITERAL) {
                 P.rec[o] = make_float4((float)x, (float)y, ux[kk], uy[kk]);
             } else {
@@ -342,7 +348,6 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
                 const float sc = (n1 <= kF1e6) ? 0.f : kVoteScale;  // zero direction never votes (:121)
                 const float Mx = ux[kk] * sc, My = uy[kk] * sc;
                 P.rec[o] = make_float4((float)x, (float)y, My, -Mx);
-                P.tq[o] = make_float2(P.tau * Mx, P.tau * My);
             }
         }
     };
@@ -392,7 +397,6 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
         for (int i = threadIdx.x; i < (tpad - tn) * kn; i += 256) {
             const int kk = i / (tpad - tn), t = tn + i - kk * (tpad - tn);
             P.rec[((size_t)bi * P.vn + k0 + kk) * P.cap + t] = make_float4(0.f, 0.f, 0.f, 0.f);
-            P.tq[((size_t)bi * P.vn + k0 + kk) * P.cap + t] = make_float2(0.f, 0.f);
         }
     }
 }
@@ -441,6 +445,7 @@ __device__ __forceinline__ void plan_image(const VoteParams& P, int bi) {
 // ------------------------------------------------------------------------------------------------------------
 // K3: hypotheses                                               (ransac_voting_gpu.py:547,554; kernel.cu:11-49)
 // ------------------------------------------------------------------------------------------------------------
+template <bool LITERAL>
 __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
     if (blockIdx.x == gridDim.x - 1) {  // one extra block per image plans its scoring work items
         plan_image(P, blockIdx.y);      // (consumed by the next launches only)
@@ -465,12 +470,10 @@ __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
             t0 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u), (uint32_t)tn);
             t1 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u + 1u), (uint32_t)tn);
         }
-        const int p0 = P.pix[(size_t)bi * P.cap + t0], p1 = P.pix[(size_t)bi * P.cap + t1];
-        const float2 d0 = P.dir[((size_t)bi * P.vn + k) * P.cap + t0];
-        const float2 d1 = P.dir[((size_t)bi * P.vn + k) * P.cap + t1];
-        const int y0 = p0 / P.w, y1 = p1 / P.w;
-        hyp_intersect(d0.x, d0.y, (float)(p0 - y0 * P.w), (float)y0, d1.x, d1.y, (float)(p1 - y1 * P.w), (float)y1,
-                      hx, hy);
+        const float4 q0 = P.rec[((size_t)bi * P.vn + k) * P.cap + t0];  // (x, y, direction) of the two pixels
+        const float4 q1 = P.rec[((size_t)bi * P.vn + k) * P.cap + t1];
+        const float2 d0 = rec_dir<LITERAL>(q0), d1 = rec_dir<LITERAL>(q1);
+        hyp_intersect(d0.x, d0.y, q0.x, q0.y, d1.x, d1.y, q1.x, q1.y, hx, hy);
     }
     P.hyp[((size_t)bi * P.vn + k) * P.hn_pad + h] = make_float2(hx, hy);
     }
@@ -518,17 +521,13 @@ __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
         for (int i = threadIdx.x; i < npx; i += 256) {
             const int p = cg * npx + i;
             float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-            float2 tq = make_float2(0.f, 0.f);
-            if (p < tpad) {
-                q = P.rec[bk * P.cap + p];
-                if (!LITERAL) tq = P.tq[bk * P.cap + p];
-            }
+            if (p < tpad) q = P.rec[bk * P.cap + p];
             if (LITERAL) {
                 s_a[i] = q;
             } else {
                 float4 a;
                 float2 b;
-                make_pixrec(q, tq, ox, oy, a, b);
+                make_pixrec(q, P.tau, ox, oy, a, b);
                 s_a[i] = a;
                 s_b[i] = b;
             }
@@ -657,15 +656,14 @@ __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
 #pragma unroll 4
     for (int t = threadIdx.x; t < tn; t += RT) {
         const float4 q = P.rec[bk * P.cap + t];
-        const float2 u = P.dir[bk * P.cap + t];
+        const float2 u = rec_dir<LITERAL>(q);
         bool in;
         if (LITERAL) {
             in = inlier_literal(q.x, q.y, u.x, u.y, wx, wy, P.thresh);
         } else {
-            const float2 tq = P.tq[bk * P.cap + t];
             float4 ra;
             float2 rb;
-            make_pixrec(q, tq, ox, oy, ra, rb);
+            make_pixrec(q, P.tau, ox, oy, ra, rb);
             in = vote_expanded(ra, rb, wx - ox, wy - oy) > 0.5f;  // the very predicate that scored
         }
         const double wgt = in ? 1.0 : 0.0;  // predicated, not branched
@@ -715,6 +713,7 @@ __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
 // ------------------------------------------------------------------------------------------------------------
 // ransac_voting_layer_v5's extra output (ransac_voting_gpu.py:846-850): fraction of the image's kept pixels that
 // vote (literal float32 test, threshold `thresh`, 0.999 in the reference) for the given points.
+template <bool LITERAL>
 __global__ __launch_bounds__(256) void confidence_kernel(VoteParams P, const float* __restrict__ pts, float thresh,
                                                          float* __restrict__ conf) {
     const int k = blockIdx.x, bi = blockIdx.y;
@@ -725,10 +724,9 @@ __global__ __launch_bounds__(256) void confidence_kernel(VoteParams P, const flo
     int n = 0;
     if (live)
         for (int t = threadIdx.x; t < tn; t += 256) {
-            const int p = P.pix[(size_t)bi * P.cap + t];
-            const int y = p / P.w;
-            const float2 u = P.dir[bk * P.cap + t];
-            n += inlier_literal((float)(p - y * P.w), (float)y, u.x, u.y, px, py, thresh) ? 1 : 0;
+            const float4 q = P.rec[bk * P.cap + t];
+            const float2 u = rec_dir<LITERAL>(q);
+            n += inlier_literal(q.x, q.y, u.x, u.y, px, py, thresh) ? 1 : 0;
         }
     n = wave_reduce_add(n);
     __shared__ int s_n[4];
@@ -902,7 +900,8 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
     }
     {   // K3
         dim3 grid((P.hn * P.vn + 255) / 256 + 1, P.b);
-        hipLaunchKernelGGL(hypothesis_kernel, grid, dim3(256), 0, s, P);
+        if (literal) hipLaunchKernelGGL(hypothesis_kernel<true>, grid, dim3(256), 0, s, P);
+        else hipLaunchKernelGGL(hypothesis_kernel<false>, grid, dim3(256), 0, s, P);
         PV_LAUNCH_CHECK();
         PV_HIP(mark(4));
     }
@@ -960,8 +959,6 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     P.bits = reinterpret_cast<uint64_t*>(base + L.off_bits);
     P.pix = reinterpret_cast<int32_t*>(base + L.off_pix);
     P.rec = reinterpret_cast<float4*>(base + L.off_rec);
-    P.tq = reinterpret_cast<float2*>(base + L.off_tq);
-    P.dir = reinterpret_cast<float2*>(base + L.off_dir);
     P.hyp = reinterpret_cast<float2*>(base + L.off_hyp);
     P.partial = reinterpret_cast<uint16_t*>(base + L.off_partial);
     P.counts = reinterpret_cast<int32_t*>(base + L.off_counts);
@@ -1023,8 +1020,6 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     L->off_bits = take(sizeof(uint64_t) * (size_t)b * L->words);
     L->off_pix = take(sizeof(int32_t) * (size_t)b * cap);
     L->off_rec = take(sizeof(float) * 4 * (size_t)b * vn * cap);
-    L->off_tq = take(sizeof(float) * 2 * (size_t)b * vn * cap);
-    L->off_dir = take(sizeof(float) * 2 * (size_t)b * vn * cap);
     L->off_hyp = take(sizeof(float) * 2 * (size_t)b * vn * L->hn_pad);
     L->off_partial = take(sizeof(uint16_t) * (size_t)b * vn * L->max_chunks * L->hn_pad);
     L->off_counts = take(sizeof(int32_t) * (size_t)b * vn * L->hn_pad);
@@ -1091,14 +1086,18 @@ static int params_for_workspace(VoteParams& P, int b, int h, int w, int vn, int 
                        &dummy, nullptr, ws, ws_bytes);
 }
 
-int pvnet_vote_confidence(const float* kpts, float thresh, float* out_conf, int b, int h, int w, int vn, int hn,
-                          int max_num, void* workspace, size_t workspace_bytes, void* stream) {
+int pvnet_vote_confidence(const float* kpts, float thresh, float* out_conf, uint32_t vote_flags, int b, int h, int w,
+                          int vn, int hn, int max_num, void* workspace, size_t workspace_bytes, void* stream) {
     if (!kpts || !out_conf) return PVNET_E_BADARG;
     VoteParams P;
     int rc = params_for_workspace(P, b, h, w, vn, hn, max_num, workspace, workspace_bytes);
     if (rc) return rc;
-    hipLaunchKernelGGL(confidence_kernel, dim3(vn, b), dim3(256), 0, static_cast<hipStream_t>(stream), P, kpts, thresh,
-                       out_conf);
+    if (vote_flags & PVNET_F_LITERAL)  // the record format the preceding vote call left in the workspace
+        hipLaunchKernelGGL(confidence_kernel<true>, dim3(vn, b), dim3(256), 0, static_cast<hipStream_t>(stream), P,
+                           kpts, thresh, out_conf);
+    else
+        hipLaunchKernelGGL(confidence_kernel<false>, dim3(vn, b), dim3(256), 0, static_cast<hipStream_t>(stream), P,
+                           kpts, thresh, out_conf);
     PV_LAUNCH_CHECK();
     return 0;
 }

@@ -34,7 +34,7 @@ class Layout(C.Structure):
     """ctypes image of ``PvnetVoteLayout`` (include/pvnet_vote.h)."""
     _fields_ = [(n, C.c_int32) for n in ("b", "h", "w", "vn", "hn", "cap", "words", "chunk", "max_chunks", "hpl",
                                           "hgroups", "hn_pad")] + \
-               [(n, C.c_size_t) for n in ("off_ctrl", "off_bits", "off_pix", "off_rec", "off_tq", "off_dir", "off_hyp",
+               [(n, C.c_size_t) for n in ("off_ctrl", "off_bits", "off_pix", "off_rec", "off_hyp",
                                           "off_partial", "off_counts", "off_win", "off_seg", "off_items", "total_bytes")] + \
                [("nseg", C.c_int32), ("wg_g", C.c_int32), ("wg_s", C.c_int32), ("reserved_", C.c_int32)]
 
@@ -71,7 +71,7 @@ def load_library() -> C.CDLL:
                                                 C.c_void_p]
     ws_tail = [C.c_int] * 6 + [C.c_void_p, C.c_size_t, C.c_void_p]
     lib.pvnet_vote_confidence.restype = C.c_int
-    lib.pvnet_vote_confidence.argtypes = [f32p, C.c_float, f32p] + ws_tail
+    lib.pvnet_vote_confidence.argtypes = [f32p, C.c_float, f32p, C.c_uint32] + ws_tail
     lib.pvnet_vote_distribution.restype = C.c_int
     lib.pvnet_vote_distribution.argtypes = [f32p, f32p] + ws_tail
     if lib.pvnet_vote_abi_version() != 1:
@@ -145,7 +145,6 @@ def _debug_views(ws: torch.Tensor, L: Layout):
         bits=view(L.off_bits, 8 * b * L.words, torch.int64, (b, L.words)),
         pix=view(L.off_pix, 4 * b * cap, torch.int32, (b, cap)),
         rec=view(L.off_rec, 16 * b * vn * cap, torch.float32, (b, vn, cap, 4)),
-        dir=view(L.off_dir, 8 * b * vn * cap, torch.float32, (b, vn, cap, 2)),
         hyp=view(L.off_hyp, 8 * b * vn * hp, torch.float32, (b, vn, hp, 2))[:, :, :L.hn],
         counts=view(L.off_counts, 4 * b * vn * hp, torch.int32, (b, vn, hp))[:, :, :L.hn],
         win=view(L.off_win, 8 * b * vn, torch.int32, (b, vn, 2)),
@@ -208,6 +207,9 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
         extras.append(status)
     if return_debug:
         d = _debug_views(ws, L)
+        # raw directions as the records carry them: fast records are (x, y, My, -Mx) with M = 2^90 * u (exact)
+        d["dir"] = d["rec"][..., 2:4] if literal else torch.stack([-d["rec"][..., 3], d["rec"][..., 2]], -1) * 2.0 ** -90
+        d["literal"] = bool(literal)
         d["status"] = status
         d["seed"] = seed
         d["workspace"] = ws
@@ -234,7 +236,8 @@ def ransac_voting_layer_v5(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
     conf = torch.empty((L.b, L.vn), dtype=torch.float32, device=out.device)
     with torch.cuda.device(out.device):
         _check(load_library().pvnet_vote_confidence(C.c_void_p(out.data_ptr()), C.c_float(conf_thresh),
-                                                    C.c_void_p(conf.data_ptr()), *_ws_tail(L, max_num, ws)),
+                                                    C.c_void_p(conf.data_ptr()), F_LITERAL if dbg["literal"] else 0,
+                                                    *_ws_tail(L, max_num, ws)),
                "pvnet_vote_confidence")
     return out, conf
 

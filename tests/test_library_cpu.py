@@ -40,8 +40,8 @@ def test_layout_baseline_config(lib):
     assert (L.b, L.vn, L.hn, L.words) == (32, 9, 1024, 4800)
     assert L.cap % 8 == 0 and 30000 < L.cap < 32000  # max_num + 8 sigma of the Bernoulli subsample
     assert L.hn_pad == L.hgroups * 64 * L.hpl >= 1024 and L.max_chunks == -(-L.cap // L.chunk)
-    offs = [L.off_ctrl, L.off_bits, L.off_pix, L.off_rec, L.off_dir, L.off_hyp, L.off_partial, L.off_counts,
-            L.off_win, L.total_bytes]
+    offs = [L.off_ctrl, L.off_seg, L.off_items, L.off_bits, L.off_pix, L.off_rec, L.off_hyp, L.off_partial,
+            L.off_counts, L.off_win, L.total_bytes]
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
     assert lib.pvnet_vote_workspace_bytes(32, 480, 640, 9, 1024, 30000) == L.total_bytes
     full = voting.vote_layout(1, 480, 640, 9, 512, 10 ** 9)
