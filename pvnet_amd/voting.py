@@ -207,8 +207,6 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
         extras.append(status)
     if return_debug:
         d = _debug_views(ws, L)
-        # raw directions as the records carry them: fast records are (x, y, My, -Mx) with M = 2^90 * u (exact)
-        d["dir"] = d["rec"][..., 2:4] if literal else torch.stack([-d["rec"][..., 3], d["rec"][..., 2]], -1) * 2.0 ** -90
         d["literal"] = bool(literal)
         d["status"] = status
         d["seed"] = seed
@@ -217,6 +215,13 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
     if stage_times:
         extras.append(times)
     return (out, *extras) if extras else out
+
+
+def debug_dir(dbg) -> torch.Tensor:
+    """raw directions [b,vn,cap,2] as the records of a ``return_debug`` result carry them: fast records are
+    (x, y, My, -Mx) with M = 2^90 * u (an exact scaling), literal records hold (x, y, ux, uy)."""
+    rec = dbg["rec"]
+    return rec[..., 2:4] if dbg["literal"] else torch.stack([-rec[..., 3], rec[..., 2]], -1) * 2.0 ** -90
 
 
 def _ws_tail(L: Layout, max_num: int, ws: torch.Tensor):

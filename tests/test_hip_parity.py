@@ -64,7 +64,7 @@ def test_compaction_order_and_vectors():
         assert tn == coords.shape[0] == int(dbg["tn0"][bi])
         pix = dbg["pix"][bi, :tn].cpu().numpy()
         np.testing.assert_array_equal(pix, (coords[:, 1] * 173 + coords[:, 0]).astype(np.int64))  # raster order
-        d = dbg["dir"][bi, :, :tn].cpu().numpy()  # [vn,tn,2]
+        d = voting.debug_dir(dbg)[bi, :, :tn].cpu().numpy()  # [vn,tn,2]
         np.testing.assert_array_equal(d.transpose(1, 0, 2), direct)
         rec = dbg["rec"][bi, :, :tn].cpu().numpy()
         np.testing.assert_array_equal(rec[0, :, 0], coords[:, 0])
