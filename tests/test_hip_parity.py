@@ -362,3 +362,92 @@ def test_demo_fixture_end_to_end_pose(demo_fixture):
     tr_cm, rot_deg = P.cm_degree_error(pose, f["pose"].astype(np.float64))
     assert tr_cm < 0.05 and rot_deg < 0.1
     assert P.projection_2d_error(pose, f["pose"].astype(np.float64), f["bb8_3d"], f["K"]) < 0.01
+
+
+# ------------------------------------------------------------------------------------------------ more edge cases
+def test_many_hypotheses_multiple_slices():
+    """hn = 4096 (estimate_voting_distribution's default) needs more than one hypothesis slice per workgroup."""
+    mask, planar, _, vnp = small_batch(b=2, first=630, h=64, w=80, radius=9)
+    m, v = to_dev(mask, planar)
+    out, dbg = voting.ransac_voting_layer_v3(m, v, 4096, inlier_thresh=0.99, seed=2, literal=True, return_debug=True)
+    assert dbg["layout"].hgroups > dbg["layout"].wg_g
+    ref, rdbg = O.ransac_voting_layer_v3(mask, vnp, 4096, inlier_thresh=0.99, seed=2, dtype=np.float32,
+                                         return_debug=True)
+    for bi, d in enumerate(rdbg):
+        np.testing.assert_array_equal(dbg["counts"][bi].cpu().numpy().T, d["counts"])
+        np.testing.assert_array_equal(dbg["win"][bi, :, 0].cpu().numpy(), d["win_idx"])
+    assert np.abs(out.cpu().numpy() - ref).max() < 1e-4
+
+
+def test_tiny_masks_and_many_keypoints():
+    h, w, vn = 48, 64, 17
+    rng = np.random.default_rng(3)
+    mask = np.zeros((3, h, w), np.int64)
+    mask[0, 10, 10:15] = 1  # exactly min_num = 5 pixels
+    mask[1, 20:23, 30:33] = 1  # 9 pixels
+    mask[2, 5:40, 7:60] = 1  # 1855 pixels, not a multiple of 8
+    kp = rng.uniform([5, 5], [w - 5, h - 5], size=(vn, 2))
+    planar = np.stack([synth.field_from_keypoints(mask[i].astype(bool), kp, "normal", rng) for i in range(3)])
+    vnp = synth.planar_to_vertex_view(planar)
+    m, v = to_dev(mask, planar)
+    out, dbg = voting.ransac_voting_layer_v3(m, v, 96, inlier_thresh=0.99, seed=5, literal=True, return_debug=True)
+    ref, rdbg = O.ransac_voting_layer_v3(mask, vnp, 96, inlier_thresh=0.99, seed=5, dtype=np.float32,
+                                         return_debug=True)
+    assert [int(x) for x in dbg["tn"]] == [5, 9, 1855]
+    for bi, d in enumerate(rdbg):
+        np.testing.assert_array_equal(dbg["counts"][bi].cpu().numpy().T, d["counts"])
+    # collinear 5-pixel mask: normal matrix of some key-points is (near-)singular in both implementations
+    ok = np.isfinite(ref).all(axis=-1) & (np.abs(ref) < 1e4).all(axis=-1)
+    assert np.abs(out.cpu().numpy() - ref)[ok].max() < 1e-2
+    assert np.abs(out.cpu().numpy()[2] - ref[2]).max() < 1e-4
+
+
+def test_full_frame_foreground_is_subsampled_to_max_num():
+    """480x640 all foreground, max_num = 30000 (the reference default): Bernoulli thinning on the device, no overflow."""
+    h, w = 480, 640
+    kp = np.array([[100.5, 200.25], [500.0, 50.0], [320.0, 240.0]])
+    fg = np.ones((h, w), bool)
+    planar = synth.field_from_keypoints(fg, kp)[None]
+    mask = fg[None].astype(np.uint8)
+    m, v = to_dev(mask, planar)
+    out, dbg = voting.ransac_voting_layer_v3(m, v, 256, inlier_thresh=0.99, seed=13, return_debug=True)
+    tn0, tn = int(dbg["tn0"][0]), int(dbg["tn"][0])
+    assert tn0 == h * w and abs(tn - 30000) < 6 * np.sqrt(30000)  # Binomial(tn0, max_num/tn0)
+    assert not (dbg["status"] & voting.S_OVERFLOW).any()
+    keep = O.subsample_keep(13, 0, h * w, 30000, tn0)
+    assert tn == int(keep.sum())  # same counter RNG as the oracle
+    np.testing.assert_array_equal(dbg["pix"][0, :tn].cpu().numpy(), np.nonzero(keep)[0])
+    assert np.abs(out[0].cpu().numpy() - kp).max() < 5e-3  # clean field
+
+
+def test_hip_graph_capture_and_replay():
+    """the C ABI only enqueues on the caller's stream (no allocation, no sync): capturable in a hipGraph."""
+    mask, planar, _, _ = small_batch(b=2, first=640, h=96, w=128, radius=14)
+    m, v = to_dev(mask, planar)
+    L = voting.vote_layout(2, 96, 128, 9, 64, 30000)
+    ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=dev())
+    out = torch.zeros((2, 9, 2), device=dev())
+    import ctypes as C
+    lib = voting.load_library()
+
+    def enqueue():
+        rc = lib.pvnet_vote_v3(C.c_void_p(m.data_ptr()), 3, (C.c_int64 * 3)(*m.stride()), C.c_void_p(v.data_ptr()),
+                               (C.c_int64 * 5)(*v.stride()), 2, 96, 128, 9, 64, C.c_float(0.99), 5, 30000,
+                               C.c_uint64(21), 0, None, 0, C.c_void_p(out.data_ptr()), None, C.c_void_p(ws.data_ptr()),
+                               C.c_size_t(L.total_bytes), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+
+    ref = voting.ransac_voting_layer_v3(m, v, 64, inlier_thresh=0.99, seed=21)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        enqueue()  # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        enqueue()
+    out.zero_()
+    g.replay()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
