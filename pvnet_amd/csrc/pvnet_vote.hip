@@ -4,24 +4,26 @@
 // (ransac_voting_layer_v3) together with the two CUDA kernels it drives,
 // src/ransac_voting_kernel.cu:11-49 (generate_hypothesis) and :88-126 (voting_for_hypothesis).
 // Not a translation: the reference runs a Python loop per image with ~40 torch launches, materialises an
-// [hn,vn,tn] uint8 inlier tensor and syncs with the host 6-8 times per image.  Here a whole batch is seven
-// launches on the caller's stream, nothing of size hn*tn ever touches HBM, and there is no host sync.
+// [hn,vn,tn] uint8 inlier tensor and syncs with the host 6-8 times per image.  Here a whole batch is six
+// launches on the caller's stream, nothing of size hn*tn ever touches HBM, and there is no host sync,
+// no allocation and no memset (DESIGN.md has the design history and the measurements behind each choice).
 //
 // Stages (one launch each, all images of the batch at once):
-//   K1 mask_bits      mask (any int dtype / f32, any strides) -> 1 bit per pixel + foreground count   [HBM read]
-//   K1b subsample     Bernoulli(max_num/tn0) thinning of the bit mask when tn0 > max_num (device decision)
-//   K2 compact        order-preserving (raster) compaction: wave ballot/popcount prefix; gathers the vn
-//                     direction vectors of each foreground pixel straight from the strided field (planar in
-//                     practice -> consecutive lanes read consecutive addresses) and writes per-(image,kp)
-//                     scoring records (x, y, mx, my) as float4                                         [HBM read]
-//   K2b plan          per-image chunk counts and the exclusive prefix of scoring work items
-//   K3 hypotheses     one thread per (image, kp, h): two pixel draws (counter RNG or caller idxs), 2x2 solve
-//   K4 score          DOMINANT, fp32 VALU bound.  "Lane owns hypotheses": every lane keeps HPL hypotheses and
-//                     their counters in VGPRs; the pixel records of a chunk are wave-uniform and arrive
-//                     through the scalar cache (s_load_dwordx8/16 -> SGPR operands of the VALU ops), so the
-//                     inner loop is a pure v_sub/v_fma/v_cmp/v_addc stream with no LDS, no cross-lane traffic
-//                     and no barriers.  Work items (image, kp, hypothesis group, pixel chunk) are strided over
-//                     a persistent grid; per-chunk counts go out as uint16.
+//   K1 mask_bits      mask (any int dtype / f32, any strides) -> 1 bit per pixel + per-segment counts  [HBM read]
+//   K1b subsample     Bernoulli(max_num/tn0) thinning of the bit mask when tn0 > max_num (device decision; a
+//                     few scalar loads and exit otherwise)
+//   K2 compact        order-preserving (raster) compaction: segment counts + wave scan of word popcounts give
+//                     every kept pixel its slot; one thread per kept pixel gathers its vn direction vectors
+//                     straight from the strided field (planar in practice -> consecutive lanes read
+//                     consecutive addresses) and writes ONE float4 record per (pixel, key-point):
+//                     (x, y, My, -Mx) with M = 2^90 * direction                                        [HBM read]
+//   K3 hypotheses     one thread per (image, kp, h): two pixel draws (counter RNG or caller idxs), 2x2 solve in
+//                     the reference's float32 order; one extra block per image plans the scoring work items
+//   K4 score          DOMINANT, fp32 VALU bound: 6 VALU ops per (hypothesis, pixel) test.  "Lane owns
+//                     hypotheses": every lane keeps HPL hypotheses and their float vote counters in VGPRs; a
+//                     workgroup stages the records of its pixel chunks in LDS once and its 4 waves read them
+//                     back as broadcast ds_read_b128/b64; the vote is the CLAMPed result of the last fma.
+//                     Work items are strided over a persistent grid; per-chunk counts go out as uint16 rows.
 //   K5 select+refine  sums the chunk counts, arg-max with first-index tie-break (wave shuffles), recomputes the
 //                     winner's inliers and solves the 2x2 normal equations, accumulated in float64 centred on
 //                     the winner (the reference's un-centred float32 sums are ~2e-3 px noisy).
@@ -483,15 +485,18 @@ __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
 // K4: inlier scoring                                           (kernel.cu:88-126 + ransac_voting_gpu.py:557-561)
 //
 // "Lane owns hypotheses": each lane keeps HPL hypotheses and their vote counters in VGPRs and walks the pixels of
-// a chunk; 7 VALU ops per (hypothesis, pixel) test in fast mode, all on VGPR operands.
+// a chunk; 6 VALU ops per (hypothesis, pixel) test in fast mode (vote_expanded), all on VGPR operands.
 //
 // Measured on gfx950 (profiles/r01_ubench_valu.txt, r01_tune*.txt): a VALU op that takes an SGPR operand issues at
 // about half the rate of a VGPR-only one, so streaming the (wave-uniform) pixel records through the scalar cache
 // made a 7-op loop no faster than a 9-op one.  The records therefore go through LDS: a workgroup = 4 waves works on
-// ONE (image, key-point, chunk group); its 256 threads stage the chunk's records with one coalesced 16-byte and
-// one 8-byte load per thread, and every wave then reads them back as broadcast ds_read_b128 / ds_read_b64 (all
-// lanes the same address: conflict-free, LDS pipe, not VALU) -- the 4 waves cover G hypothesis groups x S chunks.
-// Work items are strided over a persistent grid; the per-chunk counts leave as coalesced uint16 rows.
+// ONE (image, key-point, chunk group) planned by K3; its 256 threads load the chunk's records (one coalesced
+// 16-byte load per thread), turn them into the expanded-form constants about the image origin and park them in
+// LDS; every wave then reads them back as broadcast ds_read_b128 + ds_read_b64 (all lanes the same address:
+// conflict-free, LDS pipe, not VALU) -- the 4 waves cover G hypothesis groups x S chunks.  Work items are strided
+// over a persistent grid; the per-chunk counts leave as coalesced uint16 rows.  At batch 32 the kernel issues
+// ~139 M VALU wave-instructions in ~150 us = ~91 % of the 2-cycles-per-instruction bound at the 1.97 GHz it
+// sustains (profiles/r01_streamk_experiment.txt), so what is left is the op count, not the schedule.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int NB = 4;  // pixels per inner-loop step (4 ds_read_b128 + 4 ds_read_b64 in flight)
 
