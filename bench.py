@@ -121,16 +121,25 @@ def main():
     voting.load_library()
 
     sets = make_inputs(rank, a.buffers, a.radius, not a.clean, dev)
-    gathered = torch.empty((world * BATCH, VN, 2), dtype=torch.float32, device=dev) if world > 1 else None
+    # double-buffered gather target: the 2.3 KB all-gather of step i (RCCL stream) overlaps the voting of step i+1
+    gathered = [torch.empty((world * BATCH, VN, 2), dtype=torch.float32, device=dev) for _ in range(2)] \
+        if world > 1 else None
+    pending = []
 
     def step(i, **kw):
         m, v, _, _ = sets[i % len(sets)]
-        out = voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=1234 + i, **kw)
+        out = voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=1234 + i, image_offset=rank * BATCH,
+                                            **kw)
         if world > 1 and not kw:
-            dist.all_gather_into_tensor(gathered, out)  # the single RCCL gather of 2-D key-points over xGMI
+            # the path's single exchange: RCCL all-gather of the [32, 9, 2] key-points over xGMI
+            pending.append(dist.all_gather_into_tensor(gathered[i % 2], out, async_op=True))
+            if len(pending) > 1:
+                pending.pop(0).wait()  # step i-1's gather must be done before its buffer is reused at step i+1
         return out
 
     def fence():
+        while pending:
+            pending.pop(0).wait()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()

@@ -39,6 +39,7 @@ extern "C" {
 #define PVNET_MASK_I32  2
 #define PVNET_MASK_I64  3          /* what torch.argmax delivers (tools/demo.py:52) */
 #define PVNET_MASK_F32  4
+#define PVNET_MASK_LOGITS_F32 5     /* internal: pvnet_vote_v3_logits (fused arg-max over class planes) */
 
 /* flags */
 #define PVNET_F_LITERAL   1u       /* score with the reference's float32 operation order (sqrt + divide, one
@@ -106,6 +107,18 @@ int pvnet_vote_v3(const void* mask, int mask_dtype, const int64_t mask_strides[3
                   uint64_t seed, int image_base, const int32_t* idxs, uint32_t flags,
                   float* out_kpts, int32_t* out_status,
                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same layer fed with the backbone's class LOGITS instead of a mask: seg_pred [b,C,h,w] float32 with element
+ * strides seg_strides[4]; foreground <=> argmax_c(seg_pred) != 0 (first maximum wins ties), i.e. the
+ * `mask = torch.argmax(seg_pred, 1)` of EvalWrapper.forward (tools/demo.py:52, tools/train_linemod.py:99-101) fused
+ * into the first kernel -- the int64 mask is never materialised. */
+int pvnet_vote_v3_logits(const float* seg_pred, const int64_t seg_strides[4], int num_classes,
+                         const float* vertex, const int64_t vertex_strides[5],
+                         int b, int h, int w, int vn, int hn,
+                         float inlier_thresh, int min_num, int max_num,
+                         uint64_t seed, int image_base, const int32_t* idxs, uint32_t flags,
+                         float* out_kpts, int32_t* out_status,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* Same call, timed stage by stage with hipEvents on `stream`; synchronises the stream before returning.
  * stage_ms (host, PVNET_NUM_STAGES floats) receives the GPU time of each stage of this call. bench/profiling only. */

@@ -57,8 +57,8 @@ constexpr int PAD = 8;                 // scoring consumes records 8 at a time; 
 
 struct VoteParams {
     const void* mask;
-    int64_t ms0, ms1, ms2;
-    int mask_dtype, mask_linear;
+    int64_t ms0, ms1, ms2, ms_c;
+    int mask_dtype, mask_linear, num_classes;
     const float* vertex;
     int64_t vs0, vs1, vs2, vs3, vs4;
     int b, h, w, vn, hn, npix, words, cap, chunk, max_chunks, hpl, hgroups, hn_pad, wg_g, wg_s;
@@ -214,7 +214,18 @@ __global__ __launch_bounds__(64 * K1_WAVES) void mask_bits_kernel(VoteParams P) 
                 const int y = p / P.w, x = p - y * P.w;
                 off = (int64_t)bi * P.ms0 + (int64_t)y * P.ms1 + (int64_t)x * P.ms2;
             }
-            v = load_fg<DT>(P.mask, off);
+            if (DT == PVNET_MASK_LOGITS_F32) {  // fused torch.argmax(seg_pred, 1) (tools/demo.py:52): first maximum wins
+                const float* sp = reinterpret_cast<const float*>(P.mask) + off;
+                float best = sp[0];
+                int arg = 0;
+                for (int c = 1; c < P.num_classes; ++c) {
+                    const float x = sp[(int64_t)c * P.ms_c];
+                    if (x > best) { best = x; arg = c; }
+                }
+                v = (arg & 0xFF) != 0;  // then .byte() != 0 (ransac_voting_gpu.py:527)
+            } else {
+                v = load_fg<DT>(P.mask, off);
+            }
         }
         f[i] = v;
     }
@@ -883,6 +894,7 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
             case PVNET_MASK_I32: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I32>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
             case PVNET_MASK_I64: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I64>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
             case PVNET_MASK_F32: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_F32>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
+            case PVNET_MASK_LOGITS_F32: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_LOGITS_F32>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
             default: return PVNET_E_BADARG;
         }
         PV_LAUNCH_CHECK();
@@ -937,7 +949,7 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
                 uint64_t seed, int image_base, const int32_t* idxs, uint32_t flags, float* out, int32_t* status,
                 void* ws, size_t ws_bytes) {
     if (!mask || !vertex || !ms || !vs || !out || !ws) return PVNET_E_BADARG;
-    if (mask_dtype < PVNET_MASK_U8 || mask_dtype > PVNET_MASK_F32) return PVNET_E_BADARG;
+    if (mask_dtype < PVNET_MASK_U8 || mask_dtype > PVNET_MASK_LOGITS_F32) return PVNET_E_BADARG;
     PvnetVoteLayout L;
     int rc = pvnet_vote_layout(b, h, w, vn, hn, max_num, &L);
     if (rc) return rc;
@@ -947,6 +959,7 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     if (!(thresh > 0.f && thresh < 1.f)) flags |= PVNET_F_LITERAL;
     char* base = static_cast<char*>(ws);
     P.mask = mask; P.ms0 = ms[0]; P.ms1 = ms[1]; P.ms2 = ms[2];
+    P.ms_c = 0; P.num_classes = 1;  // only the logits entry point sets these
     P.mask_dtype = mask_dtype;
     P.mask_linear = (ms[2] == 1 && ms[1] == w) ? 1 : 0;
     P.vertex = vertex; P.vs0 = vs[0]; P.vs1 = vs[1]; P.vs2 = vs[2]; P.vs3 = vs[3]; P.vs4 = vs[4];
@@ -1047,6 +1060,23 @@ int pvnet_vote_v3(const void* mask, int mask_dtype, const int64_t mask_strides[3
                          min_num, max_num, seed, image_base, idxs, flags, out_kpts, out_status, workspace,
                          workspace_bytes);
     if (rc) return rc;
+    return launch_all(P, static_cast<hipStream_t>(stream), nullptr);
+}
+
+int pvnet_vote_v3_logits(const float* seg_pred, const int64_t seg_strides[4], int num_classes, const float* vertex,
+                         const int64_t vertex_strides[5], int b, int h, int w, int vn, int hn, float inlier_thresh,
+                         int min_num, int max_num, uint64_t seed, int image_base, const int32_t* idxs, uint32_t flags,
+                         float* out_kpts, int32_t* out_status, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+    if (!seg_strides || num_classes < 1) return PVNET_E_BADARG;
+    const int64_t ms[3] = {seg_strides[0], seg_strides[2], seg_strides[3]};  // (b, y, x); class stride separately
+    VoteParams P;
+    int rc = fill_params(P, seg_pred, PVNET_MASK_LOGITS_F32, ms, vertex, vertex_strides, b, h, w, vn, hn,
+                         inlier_thresh, min_num, max_num, seed, image_base, idxs, flags, out_kpts, out_status,
+                         workspace, workspace_bytes);
+    if (rc) return rc;
+    P.ms_c = seg_strides[1];
+    P.num_classes = num_classes;
     return launch_all(P, static_cast<hipStream_t>(stream), nullptr);
 }
 

@@ -62,6 +62,8 @@ def load_library() -> C.CDLL:
                C.c_int, C.c_int, C.c_uint64, C.c_int, i32p, C.c_uint32, f32p, i32p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.pvnet_vote_v3.restype = C.c_int
     lib.pvnet_vote_v3.argtypes = v3_args
+    lib.pvnet_vote_v3_logits.restype = C.c_int
+    lib.pvnet_vote_v3_logits.argtypes = [f32p, i64p, C.c_int, f32p, i64p] + v3_args[5:]
     lib.pvnet_vote_v3_profiled.restype = C.c_int
     lib.pvnet_vote_v3_profiled.argtypes = v3_args + [C.POINTER(C.c_float)]
     lib.pvnet_generate_hypothesis.restype = C.c_int
@@ -222,6 +224,57 @@ def debug_dir(dbg) -> torch.Tensor:
     (x, y, My, -Mx) with M = 2^90 * u (an exact scaling), literal records hold (x, y, ux, uy)."""
     rec = dbg["rec"]
     return rec[..., 2:4] if dbg["literal"] else torch.stack([-rec[..., 3], rec[..., 2]], -1) * 2.0 ** -90
+
+
+def ransac_voting_layer_v3_from_logits(seg_pred, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99,
+                                       max_iter=20, min_num=5, max_num=30000, *, idxs=None, seed=None,
+                                       image_offset=0, literal=False, refine=True):
+    """``ransac_voting_layer_v3(torch.argmax(seg_pred, 1), vertex, ...)`` with the arg-max fused into the first
+    kernel: the class logits ``seg_pred [b,C,h,w]`` float32 are read in place and the int64 mask the reference
+    materialises (tools/demo.py:52) never exists.  Same result as the two-step call."""
+    lib = load_library()
+    if not seg_pred.is_cuda or seg_pred.dim() != 4:
+        raise RuntimeError("seg_pred must be a CUDA tensor [b,C,h,w]")
+    if seg_pred.dtype != torch.float32:
+        seg_pred = seg_pred.float()
+    b, nc, h, w = seg_pred.shape
+    fake_mask = seg_pred[:, 0]  # shape/device checks only
+    _, vertex, b, h, w, vn, hn, max_num, idxs = _prepare(fake_mask, vertex, round_hyp_num, max_num, idxs)
+    dev = vertex.device
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    flags = (F_LITERAL if literal else 0) | (0 if refine else F_NO_REFINE)
+    L = vote_layout(b, h, w, vn, hn, max_num)
+    with torch.cuda.device(dev):
+        ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=dev)
+        out = torch.empty((b, vn, 2), dtype=torch.float32, device=dev)
+        _check(lib.pvnet_vote_v3_logits(
+            C.c_void_p(seg_pred.data_ptr()), _strides(seg_pred, 4), nc, C.c_void_p(vertex.data_ptr()),
+            _strides(vertex, 5), b, h, w, vn, hn, C.c_float(inlier_thresh), int(min_num), max_num,
+            C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), int(image_offset),
+            C.c_void_p(idxs.data_ptr()) if idxs is not None else None, flags, C.c_void_p(out.data_ptr()), None,
+            C.c_void_p(ws.data_ptr()), C.c_size_t(L.total_bytes),
+            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "pvnet_vote_v3_logits")
+    return out
+
+
+class EvalWrapper(torch.nn.Module):
+    """The reference's ``EvalWrapper`` (tools/demo.py:46-55, tools/train_linemod.py:94-106) on the HIP layer:
+    backbone outputs in, key-points out; with ``use_argmax`` the arg-max is fused into the voting launch."""
+
+    def __init__(self, round_hyp_num=512, inlier_thresh=0.99, max_num=30000):
+        super().__init__()
+        self.round_hyp_num, self.inlier_thresh, self.max_num = round_hyp_num, inlier_thresh, max_num
+
+    def forward(self, seg_pred, vertex_pred, use_argmax=True):
+        vertex_pred = vertex_pred.permute(0, 2, 3, 1)
+        b, h, w, vn_2 = vertex_pred.shape
+        vertex_pred = vertex_pred.view(b, h, w, vn_2 // 2, 2)
+        if use_argmax:
+            return ransac_voting_layer_v3_from_logits(seg_pred, vertex_pred, self.round_hyp_num,
+                                                      inlier_thresh=self.inlier_thresh, max_num=self.max_num)
+        return ransac_voting_layer_v3(seg_pred, vertex_pred, self.round_hyp_num, inlier_thresh=self.inlier_thresh,
+                                      max_num=self.max_num)
 
 
 def _ws_tail(L: Layout, max_num: int, ws: torch.Tensor):

@@ -451,3 +451,25 @@ def test_hip_graph_capture_and_replay():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
+
+
+def test_fused_argmax_logits_entry():
+    """seg_pred logits in, no int64 mask: same key-points as argmax -> v3 (tools/demo.py:46-55)."""
+    mask, planar, _, _ = small_batch(b=2, first=650, h=96, w=128, radius=14)
+    m, v = to_dev(mask, planar)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    seg = torch.randn((2, 2, 96, 128), generator=g).to(dev())
+    seg[:, 1] = torch.where(m.bool(), seg[:, 0] + 1.0, seg[:, 0] - 1.0)  # argmax == mask
+    seg[0, 1, 0, :4] = seg[0, 0, 0, :4]  # ties: torch.argmax returns the first maximum -> background
+    assert torch.equal(torch.argmax(seg, 1), m)
+    ref = voting.ransac_voting_layer_v3(torch.argmax(seg, 1), v, 64, inlier_thresh=0.99, seed=9)
+    out = voting.ransac_voting_layer_v3_from_logits(seg, v, 64, inlier_thresh=0.99, seed=9)
+    assert torch.equal(ref, out)
+    three = torch.cat([seg, seg[:, :1] - 5.0], 1)  # a third class that never wins
+    assert torch.equal(ref, voting.ransac_voting_layer_v3_from_logits(three, v, 64, inlier_thresh=0.99, seed=9))
+    wrap = voting.EvalWrapper(64, 0.99)
+    torch.manual_seed(3)
+    a = wrap(seg, torch.from_numpy(planar).to(dev()))
+    torch.manual_seed(3)
+    b = voting.ransac_voting_layer_v3(m, v, 64, inlier_thresh=0.99)
+    assert torch.equal(a, b)
