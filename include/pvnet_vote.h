@@ -43,8 +43,8 @@ extern "C" {
 
 /* flags */
 #define PVNET_F_LITERAL   1u       /* score with the reference's float32 operation order (sqrt + divide, one
-                                      rounding per op): bit-exact with oracle32.  Default: the 7-op clamp-vote
-                                      form |d x u| < tan(acos(thresh)) * (d . u)  (pvnet_vote.hip: vote_fast) */
+                                      rounding per op): bit-exact with oracle32.  Default: the 6-op clamp-vote
+                                      form |d x u| < tan(acos(thresh)) * (d . u)  (pvnet_vote.hip: vote_expanded) */
 #define PVNET_F_NO_REFINE 2u       /* skip ransac_voting_gpu.py:579-595, return the winning hypotheses */
 
 /* per-(image,key-point) status bits written to out_status */

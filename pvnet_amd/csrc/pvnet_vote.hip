@@ -116,15 +116,20 @@ __device__ __forceinline__ bool inlier_literal(float cx, float cy, float nx, flo
     return ang > thresh;
 }
 
-// Fast form of the same predicate on a pre-scaled record.  With tau = sqrt(1 - thresh^2) / thresh (0 < thresh < 1):
+// Fast form of the same predicate.  With tau = sqrt(1 - thresh^2) / thresh (0 < thresh < 1) and d = h - c:
 //     cos(angle(d, u)) > thresh   <=>   |d x u| < tau * (d . u)          (scale-invariant in |u|: no normalisation)
-// The record carries M = 2^90 * u and T = tau * M, so   s = dy*Ty + (dx*Tx - |dx*My - dy*Mx|)   is 2^90 times the
-// margin: any non-zero float32 margin is then >= 1 in magnitude and the fma's CLAMP output modifier turns s into
-// exactly 1.0f (votes) or 0.0f (does not) -- the vote IS the arithmetic result: no compare, no carry, no scalar op.
-// 6 VALU ops (2 sub, mul, 3 fma) + 1 add to accumulate.  Angular resolution at the threshold is ~1e-7 rad in
-// float32, finer than the reference's own cos-based float32 test (~1e-6 rad: cos is flat where tan is steep).
+// A record carries M = 2^90 * u; with T = tau * M the quantity  s = T.d - |M x d|  is 2^90 times the margin, so any
+// non-zero float32 margin is >= 1 in magnitude and the last fma's CLAMP output modifier turns s into exactly 1.0f
+// (votes) or 0.0f (does not) -- the vote IS the arithmetic result: no compare, no carry, no scalar op.
 // Zero directions (|u| < 1e-6, kernel.cu:121) are stored as zero records and never vote; a hypothesis that sits
 // exactly on a pixel gives s = 0 and does not vote either, as in the reference.
+// The subtraction d = h - c is folded into per-pixel constants ("expanded form"):
+//     cr = hx*My - hy*Mx - Ec,  Ec = cx*My - cy*Mx          s = hx*Tx + hy*Ty - Ed - |cr|,  Ed = cx*Tx + cy*Ty
+// = 5 VALU ops (4 fma + 1 sub with |.|) + 1 add to accumulate.  Coordinates are taken relative to a per-image
+// origin inside the object (the raster-median foreground pixel), which keeps the cancellation small: measured
+// against float64 arithmetic on the benchmark data (tools/precision_study.py) this form decides 3e-8 of the pair
+// tests differently, the un-expanded 7-op form 1e-8, and the reference's own float32 sqrt/divide order 6e-7 (the
+// tan-based test resolves ~1e-7 rad at the threshold, cos-based float32 only ~1e-6: cos is flat where tan is steep).
 constexpr float kVoteScale = 0x1p90f;
 constexpr float kVoteUnscale = 0x1p-90f;
 // raw direction of a record: fast records hold (x, y, My, -Mx) with M = 2^90 * u (an exact power-of-two scaling, so
@@ -134,20 +139,6 @@ template <bool LITERAL>
 __device__ __forceinline__ float2 rec_dir(float4 q) {
     return LITERAL ? make_float2(q.z, q.w) : make_float2(-q.w * kVoteUnscale, q.z * kVoteUnscale);
 }
-__device__ __forceinline__ float vote_fast(float cx, float cy, float My, float nMx, float Tx, float Ty, float hx,
-                                           float hy) {
-    const float dx = hx - cx, dy = hy - cy;
-    const float cr = fmaf(dy, nMx, dx * My);
-    const float e = fmaf(dx, Tx, -fabsf(cr));
-    return __builtin_amdgcn_fmed3f(fmaf(dy, Ty, e), 0.f, 1.f);  // folds into the fma's clamp bit
-}
-
-// The same margin with the subtraction of the pixel coordinate folded into per-pixel constants ("expanded form"):
-//     cr = hx*My - hy*Mx - Ec,  Ec = cx*My - cy*Mx          s = hx*Tx + hy*Ty - Ed - |cr|,  Ed = cx*Tx + cy*Ty
-// 5 VALU ops (4 fma + 1 sub with |.|) + 1 add -- one fewer than vote_fast.  Coordinates are taken relative to a
-// per-image origin inside the object (the raster-median foreground pixel), which keeps the cancellation small:
-// measured against float64 arithmetic on the benchmark data (tools/precision_study.py) this form flips 3e-8 of the
-// pair tests, vote_fast 1e-8, and the reference's own float32 sqrt/divide order 6e-7.
 // per-pixel constants as staged in LDS: a = (My, -Mx, -Ec, Tx) [ds_read_b128], b = (Ty, -Ed) [ds_read_b64]
 __device__ __forceinline__ void make_pixrec(float4 q, float tau, float ox, float oy, float4& a, float2& b) {
     const float cx = q.x - ox, cy = q.y - oy;  // exact: integer pixel coordinates
