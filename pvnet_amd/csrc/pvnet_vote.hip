@@ -49,7 +49,8 @@ enum { C_TN0 = 0, C_TN = 1, C_STATUS = 2, C_ITEM_BASE = 3, C_NCHUNKS = 4, C_OX =
 constexpr int SEG_WORDS = 64;          // a segment = 64 words = 4096 pixels: the unit of K1 / K1b / K2 workgroups
 constexpr int K1_WAVES = 16;            // waves per K1 workgroup (one workgroup = one segment): measured 4 -> 22.5 us,
                                         // 8 -> 20.6 us, 16 -> 19.4 us for the 78.6 MB int64 masks of a batch of 32
-constexpr int K1B_WAVES = 4;            // K1b (usually a no-op): small workgroups
+constexpr int K1B_WAVES = 4;            // K1b (usually a no-op): small workgroups,
+constexpr int K1B_BLOCKS = 8;           // ... a handful per image, each walking nseg / 8 segments when thinning
 constexpr int K1B_WORDS_PER_WAVE = SEG_WORDS / K1B_WAVES;
 constexpr int K1_WORDS_PER_WAVE = SEG_WORDS / K1_WAVES;  // independent loads in flight per lane
 constexpr int K2_WORDS_PER_BLOCK = SEG_WORDS;
@@ -243,39 +244,41 @@ __global__ __launch_bounds__(64 * K1_WAVES) void mask_bits_kernel(VoteParams P) 
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * K1B_WAVES) void subsample_kernel(VoteParams P) {
     const int bi = blockIdx.y;
-    // tn0 = sum of this image's segment counts; every wave reduces it for itself (no barrier, no atomics).
-    // The counts this launch reads are K1's; blocks of this launch overwrite only their OWN segment's count,
-    // and only after every wave of the block has passed this point (the barrier below) -- but other blocks may
-    // already have thinned theirs, so the unthinned total is kept by K1 in a second array.
+    // tn0 = sum of this image's segment counts as K1 wrote them (seg0: blocks of this launch rewrite only seg).
+    // Every wave reduces it for itself: no barrier, no atomics.  K1B_BLOCKS blocks per image: in the common case
+    // (nothing to thin) the launch is a few hundred blocks that load ~75 ints and exit.
     int tn0 = 0;
     for (int j = threadIdx.x & 63; j < P.nseg; j += 64) tn0 += P.seg0[bi * P.nseg + j];
     tn0 = __builtin_amdgcn_readfirstlane(wave_reduce_add(tn0));
-    if (tn0 <= P.max_num) return;  // wave-uniform: the common case costs a few loads
+    if (tn0 <= P.max_num) return;  // wave-uniform
     const float p = (float)P.max_num / (float)tn0;
     const double t = ceil((double)p * 4294967296.0);
     if (t >= 4294967296.0) return;
     const uint32_t thr = (uint32_t)t;
     const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_SUB, (uint32_t)(P.image_base + bi));
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int word0 = (blockIdx.x * K1B_WAVES + wave) * K1B_WORDS_PER_WAVE;
-    int cnt = 0;
-    for (int i = 0; i < K1B_WORDS_PER_WAVE; ++i) {
-        const int j = word0 + i;
-        if (j >= P.words) break;
-        const unsigned long long word = P.bits[(size_t)bi * P.words + j];
-        if (word == 0) continue;
-        const bool keep = ((word >> lane) & 1ull) && pvnet_rng_at(key, (uint32_t)(j * 64 + lane)) < thr;
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) P.bits[(size_t)bi * P.words + j] = m;
-        cnt += __popcll(m);
-    }
     __shared__ int s_cnt[K1B_WAVES];
-    if (lane == 0) s_cnt[wave] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int t = 0;
-        for (int i = 0; i < K1B_WAVES; ++i) t += s_cnt[i];
-        P.seg[bi * P.nseg + blockIdx.x] = t;
+    for (int sgi = blockIdx.x; sgi < P.nseg; sgi += gridDim.x) {  // this block's segments
+        const int word0 = (sgi * K1B_WAVES + wave) * K1B_WORDS_PER_WAVE;
+        int cnt = 0;
+        for (int i = 0; i < K1B_WORDS_PER_WAVE; ++i) {
+            const int j = word0 + i;
+            if (j >= P.words) break;
+            const unsigned long long word = P.bits[(size_t)bi * P.words + j];
+            if (word == 0) continue;
+            const bool keep = ((word >> lane) & 1ull) && pvnet_rng_at(key, (uint32_t)(j * 64 + lane)) < thr;
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) P.bits[(size_t)bi * P.words + j] = m;
+            cnt += __popcll(m);
+        }
+        if (lane == 0) s_cnt[wave] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tt = 0;
+            for (int i = 0; i < K1B_WAVES; ++i) tt += s_cnt[i];
+            P.seg[bi * P.nseg + sgi] = tt;
+        }
+        __syncthreads();
     }
 }
 
@@ -891,7 +894,8 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
         PV_LAUNCH_CHECK();
         PV_HIP(mark(1));
         if (P.max_num < P.npix) {  // host-known: subsampling can only trigger when max_num < h*w
-            hipLaunchKernelGGL(subsample_kernel, grid, dim3(64 * K1B_WAVES), 0, s, P);
+            hipLaunchKernelGGL(subsample_kernel, dim3(P.nseg < K1B_BLOCKS ? P.nseg : K1B_BLOCKS, P.b), dim3(64 * K1B_WAVES),
+                               0, s, P);
             PV_LAUNCH_CHECK();
         }
         PV_HIP(mark(2));
