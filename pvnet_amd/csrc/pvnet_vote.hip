@@ -50,7 +50,8 @@ constexpr int SEG_WORDS = 64;          // a segment = 64 words = 4096 pixels: th
 constexpr int K1_WAVES = 16;            // waves per K1 workgroup (one workgroup = one segment): measured 4 -> 22.5 us,
                                         // 8 -> 20.6 us, 16 -> 19.4 us for the 78.6 MB int64 masks of a batch of 32
 constexpr int K1B_WAVES = 4;            // K1b (usually a no-op): small workgroups,
-constexpr int K1B_BLOCKS = 8;           // ... a handful per image, each walking nseg / 8 segments when thinning
+constexpr int K1B_BLOCKS = 8;           // ... at least this many per image (more for small batches), each walking
+                                        // its share of the segments when thinning is needed
 constexpr int K1B_WORDS_PER_WAVE = SEG_WORDS / K1B_WAVES;
 constexpr int K1_WORDS_PER_WAVE = SEG_WORDS / K1_WAVES;  // independent loads in flight per lane
 constexpr int K2_WORDS_PER_BLOCK = SEG_WORDS;
@@ -183,7 +184,8 @@ __device__ __forceinline__ bool load_fg(const void* m, int64_t off) {
     if (DT == PVNET_MASK_U8) return reinterpret_cast<const uint8_t*>(m)[off] != 0;
     if (DT == PVNET_MASK_I16) return (reinterpret_cast<const uint16_t*>(m)[off] & 0xFFu) != 0;
     if (DT == PVNET_MASK_I32) return (reinterpret_cast<const uint32_t*>(m)[off] & 0xFFu) != 0;
-    if (DT == PVNET_MASK_I64) return (reinterpret_cast<const uint64_t*>(m)[off] & 0xFFull) != 0;
+    if (DT == PVNET_MASK_I64)  // read once, never again: non-temporal (keeps the 78 MB of a batch out of L2 / MALL)
+        return (__builtin_nontemporal_load(reinterpret_cast<const uint64_t*>(m) + off) & 0xFFull) != 0;
     const float v = reinterpret_cast<const float*>(m)[off];  // torch .byte() of a float: truncate, wrap
     return (static_cast<long long>(v) & 0xFF) != 0;
 }
@@ -894,8 +896,10 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
         PV_LAUNCH_CHECK();
         PV_HIP(mark(1));
         if (P.max_num < P.npix) {  // host-known: subsampling can only trigger when max_num < h*w
-            hipLaunchKernelGGL(subsample_kernel, dim3(P.nseg < K1B_BLOCKS ? P.nseg : K1B_BLOCKS, P.b), dim3(64 * K1B_WAVES),
-                               0, s, P);
+            int bpi = (640 + P.b - 1) / P.b;  // blocks per image: a few hundred blocks in total, whatever the batch
+            bpi = bpi < K1B_BLOCKS ? K1B_BLOCKS : bpi;
+            bpi = bpi > P.nseg ? P.nseg : bpi;
+            hipLaunchKernelGGL(subsample_kernel, dim3(bpi, P.b), dim3(64 * K1B_WAVES), 0, s, P);
             PV_LAUNCH_CHECK();
         }
         PV_HIP(mark(2));
