@@ -122,6 +122,19 @@ void ref_voting_counts(const float* direct, const float* coords, const float* hy
     }
 }
 
+/* per-thread scratch that only ever grows: bench.py runs one image per host thread, and hundreds of threads
+ * doing 400 KB malloc/free pairs (= mmap/munmap) serialise on the kernel's address-space lock */
+static void* scratch(void** buf, size_t* cap, size_t need) {
+    if (need > *cap) {
+        free(*buf);
+        *buf = malloc(need);
+        *cap = *buf ? need : 0;
+    }
+    return *buf;
+}
+static __thread void* tl_buf[5];
+static __thread size_t tl_cap[5];
+
 /* Whole layer for a batch.  fg: [b,h,w] uint8 foreground flags (caller applies mask.byte()!=0);
  * vertex element (bi,y,x,k,c) at vertex[bi*vs[0]+y*vs[1]+x*vs[2]+k*vs[3]+c*vs[4]] (strides in elements);
  * idxs: NULL (counter RNG) or [b,hn,vn,2]; out [b,vn,2]; win_idx/win_cnt [b,vn] optional.
@@ -142,8 +155,8 @@ int ref_vote_v3(const uint8_t* fg, const float* vertex, const int64_t* vs, int b
             double t = ceil((double)p * 4294967296.0);
             thr = t >= 4294967296.0 ? (1ull << 32) : (uint64_t)t;
         }
-        float* coords = (float*)malloc(sizeof(float) * 2 * (size_t)tn0);
-        float* direct = (float*)malloc(sizeof(float) * 2 * (size_t)vn * tn0);
+        float* coords = (float*)scratch(&tl_buf[0], &tl_cap[0], sizeof(float) * 2 * (size_t)tn0);
+        float* direct = (float*)scratch(&tl_buf[1], &tl_cap[1], sizeof(float) * 2 * (size_t)vn * tn0);
         int tn = 0;
         for (int y = 0; y < h; ++y)                                                 /* :542-546, raster order */
             for (int x = 0; x < w; ++x) {
@@ -159,13 +172,13 @@ int ref_vote_v3(const uint8_t* fg, const float* vertex, const int64_t* vs, int b
                 }
                 ++tn;
             }
-        if (tn == 0) { free(coords); free(direct); continue; }
-        int32_t* ix = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)hn * vn);      /* :547 */
+        if (tn == 0) continue;
+        int32_t* ix = (int32_t*)scratch(&tl_buf[2], &tl_cap[2], sizeof(int32_t) * 2 * (size_t)hn * vn);  /* :547 */
         for (int i = 0; i < hn * vn * 2; ++i)
             ix[i] = idxs ? idxs[(size_t)bi * hn * vn * 2 + i]
                          : (int32_t)(((uint64_t)ref_rng_u32(seed, TAG_HYP, (uint32_t)bi, (uint32_t)i) * (uint64_t)tn) >> 32);
-        float* hyp = (float*)malloc(sizeof(float) * 2 * (size_t)hn * vn);
-        int32_t* counts = (int32_t*)malloc(sizeof(int32_t) * (size_t)hn * vn);
+        float* hyp = (float*)scratch(&tl_buf[3], &tl_cap[3], sizeof(float) * 2 * (size_t)hn * vn);
+        int32_t* counts = (int32_t*)scratch(&tl_buf[4], &tl_cap[4], sizeof(int32_t) * (size_t)hn * vn);
         ref_generate_hypothesis(direct, coords, ix, hyp, tn, vn, hn);               /* :554 */
         ref_voting_counts(direct, coords, hyp, counts, tn, vn, hn, thresh);         /* :557-561 */
         for (int k = 0; k < vn; ++k) {
@@ -191,7 +204,6 @@ int ref_vote_v3(const uint8_t* fg, const float* vertex, const int64_t* vs, int b
             o[k * 2] = (float)((d * r0 - bb * r1) / det);
             o[k * 2 + 1] = (float)((-bb * r0 + a * r1) / det);
         }
-        free(coords); free(direct); free(ix); free(hyp); free(counts);
     }
     return 0;
 }
