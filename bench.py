@@ -81,6 +81,25 @@ def measured_traffic(kernel):
         return None
 
 
+def usable_cores():
+    """logical CPUs this process may actually use: affinity mask and cgroup CPU quota (the GPU boxes expose 256
+    logical CPUs but cap the container at a fraction of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(sets, seconds):
     """the oracle (plain-C port) on a bounded sample of the same workload -- reported, never the target.
     All cores: one image per worker thread (images are independent; ctypes releases the GIL; the C code runs
@@ -92,7 +111,7 @@ def cpu_baseline(sets, seconds):
     _, _, mask, planar = sets[0]
     vnp = synth.planar_to_vertex_view(planar)
     fg = O.foreground(mask)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
 
     def one(i):
         cref.set_num_threads(1)  # per-thread OpenMP setting: this worker runs the C code on one core
@@ -120,7 +139,8 @@ def cpu_baseline(sets, seconds):
     el = time.perf_counter() - t0
     return {"value": n / el, "unit": "votings/s", "cores": cores, "kind": "port", "value_1_core": one_core,
             "sample": f"{n} images of the bench workload (480x640, 9 kpts, 1024 hyp) in {el:.1f} s on {cores} worker "
-                      f"threads (one image each, oracle/oracle_c/pvnet_vote_ref.c); {n1} images on one core"}
+                      f"threads (one image each, oracle/oracle_c/pvnet_vote_ref.c; host shows {os.cpu_count()} logical "
+                      f"cpus, {cores} usable under its cgroup quota / affinity); {n1} images on one core"}
 
 
 def main():
