@@ -925,7 +925,7 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
         const long long max_items =
             (long long)P.b * P.vn * (P.hgroups / P.wg_g) * ((P.max_chunks + P.wg_s - 1) / P.wg_s);
         const int wgs_per_cu = env_int("PVNET_SCORE_WGS_PER_CU", 8);
-        long long wgs = (long long)num_cus() * wgs_per_cu;
+        long long wgs = wgs_per_cu > 0 ? (long long)num_cus() * wgs_per_cu : max_items;  // 0: one workgroup per item
         if (wgs > max_items) wgs = max_items;
         if (wgs < 1) wgs = 1;
         int rc = literal ? launch_score<true>(P, dim3((unsigned)wgs), s) : launch_score<false>(P, dim3((unsigned)wgs), s);
