@@ -473,3 +473,32 @@ def test_fused_argmax_logits_entry():
     torch.manual_seed(3)
     b = voting.ransac_voting_layer_v3(m, v, 64, inlier_thresh=0.99)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_randomised_shapes_literal_vs_c_oracle(case):
+    """property sweep: random image sizes, key-point counts, hypothesis counts, thresholds and thinning limits; the
+    literal path must reproduce the C oracle's winners and inlier counts exactly."""
+    rng = np.random.default_rng(1000 + case)
+    h, w = int(rng.integers(24, 200)), int(rng.integers(24, 260))
+    vn = int(rng.integers(1, 13))
+    hn = int(rng.choice([16, 40, 64, 129, 300, 777]))
+    b = int(rng.integers(1, 5))
+    radius = int(rng.integers(4, max(5, min(h, w) // 3)))
+    thresh = float(rng.choice([0.9, 0.99, 0.999]))
+    max_num = int(rng.choice([30000, 200, 60]))
+    mask, planar, _ = synth.make_batch(b, first_index=2000 + 7 * case, h=h, w=w, vn=vn, radius=radius, noise=True,
+                                       background="normal", mask_dtype=np.uint8)
+    vnp = synth.planar_to_vertex_view(planar)
+    m, v = to_dev(mask, planar)
+    seed = 50 + case
+    out, dbg = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, max_num=max_num, seed=seed, literal=True,
+                                             return_debug=True)
+    ref, wi, wc = cref.vote_v3(O.foreground(mask), vnp, hn, thresh, max_num=max_num, seed=seed, return_winners=True)
+    live = dbg["nchunks"].cpu().numpy() > 0  # images that passed the min_num gate
+    np.testing.assert_array_equal(dbg["win"][:, :, 0].cpu().numpy()[live], wi[live])
+    np.testing.assert_array_equal(dbg["win"][:, :, 1].cpu().numpy()[live], wc[live])
+    good = np.isfinite(ref).all(-1) & (np.abs(ref) < 1e5).all(-1)  # near-singular fits can blow up on both sides
+    assert np.abs(out.cpu().numpy() - ref)[good].max() < 2e-3 * max(1.0, np.abs(ref[good]).max() / 100)
+    fast = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, max_num=max_num, seed=seed)
+    assert torch.isfinite(fast).all()
