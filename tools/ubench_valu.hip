@@ -88,6 +88,100 @@ __global__ __launch_bounds__(256) void k_pair_pk(float* out, float cx, float cy,
     out[blockIdx.x * 256 + threadIdx.x] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
 }
 
+
+// ---- the two candidate scoring loops, both with VGPR-only VALU operands and LDS-broadcast "other side" ----
+// (a) lane owns 8 hypotheses, pixel records broadcast from LDS: 6 VALU per test (the shipped loop)
+__global__ __launch_bounds__(256) void k_clamp6(float* out, int npix, int reps) {
+    __shared__ float4 s_a[1024];
+    __shared__ float2 s_b[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        s_a[i] = make_float4(0.5f + i, -0.25f * i, 3.f - i, 0.125f * i);
+        s_b[i] = make_float2(0.75f - i, 10.f + i);
+    }
+    __syncthreads();
+    float hx[8], hy[8], cnt[8];
+    for (int j = 0; j < 8; ++j) { hx[j] = threadIdx.x + j; hy[j] = threadIdx.x * 0.5f - j; cnt[j] = 0.f; }
+    for (int r = 0; r < reps; ++r)
+        for (int i = 0; i < npix; i += 4) {
+            float4 qa[4]; float2 qb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { qa[u] = s_a[i + u]; qb[u] = s_b[i + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float cr = fmaf(hx[j], qa[u].x, fmaf(hy[j], qa[u].y, qa[u].z));
+                    const float t = qb[u].y - fabsf(cr);
+                    cnt[j] += __builtin_amdgcn_fmed3f(fmaf(hx[j], qa[u].w, fmaf(hy[j], qb[u].x, t)), 0.f, 1.f);
+                }
+        }
+    float s = 0;
+    for (int j = 0; j < 8; ++j) s += cnt[j];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+// (b) lane owns PPL pixels (6 VGPRs each), hypotheses broadcast from LDS: 4 fma + 1 v_cmp (|cr| as a source
+//     modifier, wave mask to an SGPR pair) per test on the VALU, s_bcnt1 + s_add on the scalar unit
+template <int PPL>
+__global__ __launch_bounds__(256) void k_ballot5(float* out, int nhyp, int reps, float sd) {
+    __shared__ float2 s_h[1024];
+    __shared__ int s_cnt[4][1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) s_h[i] = make_float2(0.5f + i, 3.f - 0.25f * i);
+    __syncthreads();
+    float A[PPL], B[PPL], C[PPL], D[PPL], E[PPL], F[PPL];
+    for (int u = 0; u < PPL; ++u) {
+        A[u] = sd * (threadIdx.x + u); B[u] = sd * (threadIdx.x * 0.5f - u); C[u] = sd * (1.f + u + threadIdx.x);
+        D[u] = sd * (0.25f * threadIdx.x - u); E[u] = sd * (7.f - u - threadIdx.x); F[u] = sd * (threadIdx.x - 100.f - u);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int r = 0; r < reps; ++r)
+        for (int h = 0; h < nhyp; h += 2) {
+            const float4 hv = *reinterpret_cast<const float4*>(&s_h[h]);  // two hypotheses per broadcast read
+            int c0 = 0, c1 = 0;
+#pragma unroll
+            for (int u = 0; u < PPL; ++u) {
+                const float cr0 = fmaf(hv.x, A[u], fmaf(hv.y, B[u], C[u]));
+                const float d0 = fmaf(hv.x, D[u], fmaf(hv.y, E[u], F[u]));
+                c0 += __builtin_popcountll(__builtin_amdgcn_fcmpf(d0, fabsf(cr0), 2 /* FCMP_OGT */));
+                const float cr1 = fmaf(hv.z, A[u], fmaf(hv.w, B[u], C[u]));
+                const float d1 = fmaf(hv.z, D[u], fmaf(hv.w, E[u], F[u]));
+                c1 += __builtin_popcountll(__builtin_amdgcn_fcmpf(d1, fabsf(cr1), 2));
+            }
+            if (lane == 0) *reinterpret_cast<int2*>(&s_cnt[wave][h]) = make_int2(c0, c1);
+        }
+    __syncthreads();
+    int s = 0;
+    for (int i = lane; i < nhyp; i += 64) s += s_cnt[wave][i];
+    out[blockIdx.x * 256 + threadIdx.x] = (float)s;
+}
+
+
+// (c) issue cost of v_cmp_*_e64 writing an SGPR pair: 4 fma + 1 compare whose mask is discarded (no SALU at all)
+template <int MODE>  // 0: v_cmp_e64 -> SGPR pair, 1: v_cmp_e32 -> vcc, 2: no compare (4 fma + 1 v_max)
+__global__ __launch_bounds__(256) void k_cmpcost(float* out, int nhyp, int reps, float sd) {
+    __shared__ float2 s_h[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) s_h[i] = make_float2(0.5f + i, 3.f - 0.25f * i);
+    __syncthreads();
+    float A[8], B[8], C[8], D[8], E[8], F[8];
+    for (int u = 0; u < 8; ++u) {
+        A[u] = sd * (threadIdx.x + u); B[u] = sd * (threadIdx.x * 0.5f - u); C[u] = sd * (1.f + u + threadIdx.x);
+        D[u] = sd * (0.25f * threadIdx.x - u); E[u] = sd * (7.f - u - threadIdx.x); F[u] = sd * (threadIdx.x - 100.f - u);
+    }
+    float sink = 0.f;
+    for (int r = 0; r < reps; ++r)
+        for (int h = 0; h < nhyp; ++h) {
+            const float2 hv = s_h[h];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float cr0 = fmaf(hv.x, A[u], fmaf(hv.y, B[u], C[u]));
+                const float d0 = fmaf(hv.x, D[u], fmaf(hv.y, E[u], F[u]));
+                if (MODE == 0) { unsigned long long m; asm volatile("v_cmp_gt_f32_e64 %0, %1, |%2|" : "=s"(m) : "v"(d0), "v"(cr0)); }
+                else if (MODE == 1) { asm volatile("v_cmp_gt_f32_e32 vcc, %0, %1" : : "v"(d0), "v"(cr0) : "vcc"); }
+                else { float t; asm volatile("v_max_f32 %0, %1, |%2|" : "=v"(t) : "v"(d0), "v"(cr0)); }
+            }
+        }
+    out[blockIdx.x * 256 + threadIdx.x] = sink;
+}
+
 template <typename F>
 float time_kernel(F launch, int reps) {
     hipEvent_t e0, e1;
@@ -125,6 +219,27 @@ int main(int argc, char** argv) {
         printf("waves/SIMD %d  pair9 (9 ops)  : %8.3f ms  %7.2f Tpairs/s  %6.1f Tinstr-lanes/s\n", wpc, t, lanes * ITER * 4 / t / 1e9, lanes * ITER * 36 / t / 1e9);
         t = time_kernel([&] { hipLaunchKernelGGL(k_pair_pk, g, b, 0, 0, out, 3.f, 4.f, 0.6f, 0.8f); }, 5);
         printf("waves/SIMD %d  pair_pk (12/2) : %8.3f ms  %7.2f Tpairs/s\n", wpc, t, lanes * ITER * 4 / t / 1e9);
+    }
+    // candidate scoring loops: same number of pair tests each (256 threads x 8 x 1024 x reps per workgroup)
+    for (int wpc = 2; wpc <= 8; wpc *= 2) {
+        dim3 g(cus * wpc), b(256);
+        const int reps = 8;
+        const double tests = (double)g.x * 256 * 8 * 1024 * reps;
+        float t;
+        t = time_kernel([&] { hipLaunchKernelGGL(k_clamp6, g, b, 0, 0, out, 1024, reps); }, 5);
+        printf("waves/SIMD %d  clamp6 lane-owns-hyps (8/lane)   : %8.3f ms  %7.2f Tpairs/s\n", wpc, t, tests / t / 1e9);
+        t = time_kernel([&] { hipLaunchKernelGGL(k_ballot5<8>, g, b, 0, 0, out, 1024, reps, 1.37f); }, 5);
+        printf("waves/SIMD %d  ballot5 lane-owns-pixels (8/lane): %8.3f ms  %7.2f Tpairs/s\n", wpc, t, tests / t / 1e9);
+        t = time_kernel([&] { hipLaunchKernelGGL(k_ballot5<4>, g, b, 0, 0, out, 1024, 2 * reps, 1.37f); }, 5);
+        printf("waves/SIMD %d  ballot5 lane-owns-pixels (4/lane): %8.3f ms  %7.2f Tpairs/s\n", wpc, t, tests / t / 1e9);
+        t = time_kernel([&] { hipLaunchKernelGGL(k_ballot5<16>, g, b, 0, 0, out, 1024, reps / 2, 1.37f); }, 5);
+        printf("waves/SIMD %d  ballot5 lane-owns-pixels (16/lane): %8.3f ms  %7.2f Tpairs/s\n", wpc, t, tests / t / 1e9);
+        t = time_kernel([&] { hipLaunchKernelGGL(k_cmpcost<0>, g, b, 0, 0, out, 1024, reps, 1.37f); }, 5);
+        printf("waves/SIMD %d  4 fma + v_cmp_e64->sgpr (discarded): %8.3f ms  %7.2f Tpairs/s\n", wpc, t, tests / t / 1e9);
+        t = time_kernel([&] { hipLaunchKernelGGL(k_cmpcost<1>, g, b, 0, 0, out, 1024, reps, 1.37f); }, 5);
+        printf("waves/SIMD %d  4 fma + v_cmp_e32->vcc  (discarded): %8.3f ms  %7.2f Tpairs/s\n", wpc, t, tests / t / 1e9);
+        t = time_kernel([&] { hipLaunchKernelGGL(k_cmpcost<2>, g, b, 0, 0, out, 1024, reps, 1.37f); }, 5);
+        printf("waves/SIMD %d  4 fma + v_max (5 plain VALU)       : %8.3f ms  %7.2f Tpairs/s\n", wpc, t, tests / t / 1e9);
     }
     return 0;
 }
