@@ -456,12 +456,19 @@ __device__ __forceinline__ void plan_image(const VoteParams& P, int bi) {
 // ------------------------------------------------------------------------------------------------------------
 template <bool LITERAL>
 __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
-    if (blockIdx.x == gridDim.x - 1) {  // one extra block per image plans its scoring work items
-        plan_image(P, blockIdx.y);      // (consumed by the next launches only)
+    // Workgroups go to the 8 XCDs round-robin by linear id; every block of image bi is placed on XCD bi % 8 so that
+    // the two random 16-byte record reads per hypothesis (several per 128-byte line of the image's records) hit
+    // that XCD's L2 after the first touch instead of crossing the fabric once per XCD.
+    const int nb = (P.hn * P.vn + 255) / 256 + 1;  // blocks per image, the last one plans
+    const int slot = blockIdx.x >> 3;
+    const int bi = (slot / nb) * 8 + (blockIdx.x & 7);
+    const int blk = slot % nb;
+    if (bi >= P.b) return;
+    if (blk == nb - 1) {      // one extra block per image plans its scoring work items
+        plan_image(P, bi);    // (consumed by the next launches only)
         return;
     }
-    const int bi = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blk * 256 + threadIdx.x;
     const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
     const bool live = P.ctrl[bi * CTRL_STRIDE + C_TN0] >= P.min_num && tn > 0;  // gates of :531-534
     if (i < P.hn * P.vn) {
@@ -614,23 +621,37 @@ __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
         for (int h = threadIdx.x; h < P.hn; h += RT) P.counts[bk * P.hn_pad + h] = 0;
         return;
     }
-    // ---- counts = sum over chunks; winner = first maximum (:561-562)
+    // ---- counts = sum over chunks; winner = first maximum (:561-562).  A thread sums two adjacent hypotheses
+    // (one 32-bit load per chunk row) with eight loads in flight: the rows are latency-, not bandwidth-bound.
     unsigned long long best = 0;
-    for (int h = threadIdx.x; h < P.hn; h += RT) {
-        const uint16_t* pp = P.partial + bk * P.max_chunks * P.hn_pad + h;
-        int s0 = 0, s1 = 0, s2 = 0, s3 = 0;  // four independent chains: chunk loads overlap instead of serialising
+    const size_t row = (size_t)(P.hn_pad >> 1);  // hn_pad is even
+    for (int h2 = threadIdx.x; 2 * h2 < P.hn; h2 += RT) {
+        const uint32_t* pp = reinterpret_cast<const uint32_t*>(P.partial + bk * P.max_chunks * P.hn_pad) + h2;
+        int lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
         int c = 0;
-        for (; c + 4 <= nch; c += 4) {
-            s0 += pp[(size_t)c * P.hn_pad];
-            s1 += pp[(size_t)(c + 1) * P.hn_pad];
-            s2 += pp[(size_t)(c + 2) * P.hn_pad];
-            s3 += pp[(size_t)(c + 3) * P.hn_pad];
+        for (; c + 8 <= nch; c += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = pp[(size_t)(c + u) * row];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                lo[u & 3] += (int)(v[u] & 0xFFFFu);
+                hi[u & 3] += (int)(v[u] >> 16);
+            }
         }
-        for (; c < nch; ++c) s0 += pp[(size_t)c * P.hn_pad];
-        const int sum = (s0 + s1) + (s2 + s3);
-        P.counts[bk * P.hn_pad + h] = sum;
-        const unsigned long long key = ((unsigned long long)(uint32_t)sum << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)h);
-        best = key > best ? key : best;
+        for (; c < nch; ++c) {
+            const uint32_t v = pp[(size_t)c * row];
+            lo[0] += (int)(v & 0xFFFFu);
+            hi[0] += (int)(v >> 16);
+        }
+        const int s0 = (lo[0] + lo[1]) + (lo[2] + lo[3]), s1 = (hi[0] + hi[1]) + (hi[2] + hi[3]);
+        const int h = 2 * h2;
+        *reinterpret_cast<int2*>(P.counts + bk * P.hn_pad + h) = make_int2(s0, s1);
+        const unsigned long long k0 = ((unsigned long long)(uint32_t)s0 << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)h);
+        const unsigned long long k1 =
+            ((unsigned long long)(uint32_t)s1 << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)(h + 1));
+        best = k0 > best ? k0 : best;
+        if (h + 1 < P.hn) best = k1 > best ? k1 : best;
     }
     best = wave_reduce_max(best);
     if (lane == 0) s_best[wave] = best;
@@ -915,7 +936,7 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
         PV_HIP(mark(3));
     }
     {   // K3
-        dim3 grid((P.hn * P.vn + 255) / 256 + 1, P.b);
+        dim3 grid((unsigned)(((P.hn * P.vn + 255) / 256 + 1) * ((P.b + 7) / 8) * 8));
         if (literal) hipLaunchKernelGGL(hypothesis_kernel<true>, grid, dim3(256), 0, s, P);
         else hipLaunchKernelGGL(hypothesis_kernel<false>, grid, dim3(256), 0, s, P);
         PV_LAUNCH_CHECK();
@@ -997,6 +1018,7 @@ const char* pvnet_vote_build_info(void) { return "pvnet_vote gfx950 hip " __DATE
 int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVoteLayout* L) {
     if (!L || b <= 0 || h <= 0 || w <= 0 || vn <= 0 || hn <= 0 || max_num < 0) return PVNET_E_BADARG;
     if ((long long)h * w > (1ll << 30) || b > 65535 || vn > 65535 || hn > (1 << 20)) return PVNET_E_UNSUPPORTED;
+    if ((long long)hn * vn > (1ll << 24)) return PVNET_E_UNSUPPORTED;  // grid sizes and 32-bit indices
     const long long npix = (long long)h * w;
     long long cap = npix;
     if (max_num < npix) {  // tn ~ Binomial(tn0, max_num/tn0): mean max_num, sigma <= sqrt(max_num); 8 sigma margin
