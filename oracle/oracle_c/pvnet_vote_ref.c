@@ -9,9 +9,11 @@
  *   lib/ransac_voting_gpu_layer/ransac_voting_gpu.py:514-598         ransac_voting_layer_v3 (one round; the
  *        reference's later rounds re-use the same idxs (:547 vs :552) and cannot change the result)
  *   lib/ransac_voting_gpu_layer/ransac_voting_gpu.py:503-512         b_inv (2x2)
- * The reference itself cannot be compiled here (CUDA kernels, removed ATen APIs): parity is unpinned by the
- * reference; this file is cross-checked bit-for-bit against the independent numpy float32 restatement in
- * oracle/ransac_voting_oracle.py and both against the demo-fixture known answer (tests/test_oracle.py).
+ * Pinned by the reference itself: its CUDA kernel file is compiled for gfx950 from the reference tree
+ * (make -C oracle ref -> oracle/_ref/) and tests/test_reference_kernels.py holds this file's hypotheses and inlier
+ * flags bit-equal to that device code on the MI355X; its Python driver is executed on CPU with these two functions
+ * standing in for the extension (oracle/ref_driver.py -> fixture G6).  Also cross-checked bit-for-bit against the
+ * independent numpy float32 restatement in oracle/ransac_voting_oracle.py (tests/test_oracle.py).
  *
  * It doubles as the CPU baseline ("port") that bench.py times on the host cores (OpenMP over hypotheses).
  */

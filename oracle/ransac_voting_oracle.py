@@ -10,10 +10,19 @@ This is a numpy restatement of the reference algorithm (all citations relative t
 * ``lib/ransac_voting_gpu_layer/src/ransac_voting_kernel.cu:88-126``  ``voting_for_hypothesis_kernel``
 * ``lib/ransac_voting_gpu_layer/ransac_voting_gpu.py:503-512``       ``b_inv`` (2x2 solve)
 
-PARITY PINNING.  The reference ships no tests, no golden vectors and cannot be built or run in this
-environment (CUDA-only kernels, removed ATen/torch APIs -- SURVEY.md section 8c), so the oracle cannot be
-checked against outputs of the reference itself: **parity is unpinned by the reference**.  What pins it
-instead (tests/test_oracle.py):
+PARITY PINNING.  The reference ships no tests and no golden vectors, but both halves of it are executed and
+compared:
+
+* its DEVICE CODE -- ransac_voting_kernel.cu is compiled for gfx950 where it lies in the reference tree
+  (``make -C oracle ref`` -> oracle/_ref/, header shim in oracle/ref_kernels/) and run on the MI355X:
+  tests/test_reference_kernels.py holds the plain-C restatement, this module's float32 flavour, the product's ops
+  and the product's literal mode bit-equal to it (hypotheses, inlier flags, counts, winners);
+* its PYTHON DRIVER -- ransac_voting_gpu.py is imported from the reference tree and ``ransac_voting_layer_v3``
+  executed on CPU tensors (oracle/ref_driver.py; the extension's two kernels stubbed by the C restatement above);
+  its outputs, the idxs it drew and the pixels it kept are fixture G6 (tests/golden/ref_driver_v3.npz), which this
+  module and the HIP path reproduce within 1e-3 px (tests/test_reference_driver.py).
+
+Further pins (tests/test_oracle.py):
 
 * G1 -- the reference's own demo fixture (data/demo/cat_mask.png + cat_pose.npy + cat_points_3d.txt):
   the ground-truth field built as tools/demo.py:58-71 does must vote back to the analytically projected

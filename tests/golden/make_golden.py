@@ -6,6 +6,11 @@ G1  demo_cat.npz   -- the reference's demo fixture (data/demo/): foreground mask
                       key-points = the known answer of voting on the ground-truth field (tools/demo.py:74-103,
                       lib/utils/base_utils.py:239-256).  The projection is restated here (3 lines of numpy)
                       because importing lib/utils/base_utils.py needs cv2/plyfile, absent from this image.
+G6  ref_driver_v3.npz -- outputs of the REFERENCE'S OWN ransac_voting_layer_v3 (ransac_voting_gpu.py:514-598), executed
+                      here on CPU tensors by oracle/ref_driver.py (the extension's two kernels stubbed by the C
+                      restatement, which tests/test_reference_kernels.py holds bit-equal to the reference's device code),
+                      together with what the run drew: the idxs of every live image, the pixels it kept, the rounds its
+                      confidence loop made.  Inputs are regenerated from the recorded synth parameters.
 G3  noisy_oracle.npz -- float64-oracle outputs (key-points, winner indices, winner counts) on seeded noisy
                       synthetic images with the counter-based RNG; guards the oracle itself against drift.
 """
@@ -59,9 +64,60 @@ def make_noisy():
     np.savez_compressed(os.path.join(OUT, "noisy_oracle.npz"), **flat)
 
 
+REF_DRIVER_CASES = [
+    # synth parameters, call parameters (those of ransac_voting_layer_v3), edits applied to the mask
+    dict(b=2, first_index=900, h=120, w=160, radius=15, noise=True, hn=64, kw=dict(inlier_thresh=0.99), edit="none"),
+    dict(b=3, first_index=910, h=96, w=128, radius=12, noise=True, hn=128, kw=dict(inlier_thresh=0.999),
+         edit="image1_three_pixels"),                       # fewer than min_num=5 -> zeros (:531-534)
+    dict(b=1, first_index=920, h=120, w=160, radius=22, noise=True, hn=64, kw=dict(inlier_thresh=0.99, max_num=400),
+         edit="none"),                                      # tn0 > max_num -> uniform_ < max_num/tn0 thinning (:537-540)
+    dict(b=1, first_index=930, h=96, w=128, radius=12, noise=True, hn=32,
+         kw=dict(inlier_thresh=0.99, confidence=1.0, max_iter=3), edit="none"),  # the loop runs max_iter+1 rounds
+    dict(b=1, first_index=940, h=96, w=128, radius=14, noise=False, hn=32, kw=dict(inlier_thresh=0.99), edit="none"),
+]
+
+
+def ref_driver_inputs(case):
+    """mask [b,h,w] int64, vertex view [b,h,w,vn,2] of one G6 case (shared with the tests)."""
+    from pvnet_amd import synth
+    mask, planar, kpts = synth.make_batch(case["b"], first_index=case["first_index"], h=case["h"], w=case["w"],
+                                          radius=case["radius"], background="normal", noise=case["noise"])
+    if case["edit"] == "image1_three_pixels":
+        mask[1] = 0
+        mask[1, 7, 10:13] = 1
+    return mask, synth.planar_to_vertex_view(planar), kpts
+
+
+def make_ref_driver():
+    from oracle import ref_driver
+    flat = {"ncases": np.array(len(REF_DRIVER_CASES))}
+    for ci, case in enumerate(REF_DRIVER_CASES):
+        mask, vertex, kpts = ref_driver_inputs(case)
+        out, cap = ref_driver.run_v3(mask, vertex, case["hn"], torch_seed=100 + ci, **case["kw"])
+        b, h, w = mask.shape
+        min_num = case["kw"].get("min_num", 5)
+        live = [bi for bi in range(b) if int((mask[bi].astype(np.uint8) != 0).sum()) >= min_num]
+        assert len(live) == len(cap.idxs)
+        keep = np.zeros((b, h, w), bool)
+        for j, bi in enumerate(live):
+            xy = cap.coords[j].astype(np.int64)
+            keep[bi, xy[:, 1], xy[:, 0]] = True
+        flat[f"c{ci}_out"] = out
+        flat[f"c{ci}_live"] = np.array(live)
+        flat[f"c{ci}_tn"] = np.array(cap.tn)
+        flat[f"c{ci}_rounds"] = np.array(cap.rounds)
+        flat[f"c{ci}_keep_bits"] = np.packbits(keep)
+        for j in range(len(live)):
+            flat[f"c{ci}_idxs{j}"] = cap.idxs[j].astype(np.int32)
+        print(f"ref driver case {ci}: live {live} tn {cap.tn} rounds {cap.rounds} max|out-kpt| "
+              f"{np.abs(out[live] - kpts[live]).max():.3f} px")
+    np.savez_compressed(os.path.join(OUT, "ref_driver_v3.npz"), **flat)
+
+
 if __name__ == "__main__":
     if os.path.isdir(REF):
         make_demo()
+        make_ref_driver()
     else:
-        print("no /root/reference: demo fixture not regenerated")
+        print("no /root/reference: demo and reference-driver fixtures not regenerated")
     make_noisy()

@@ -1,0 +1,145 @@
+"""GPU parity tests against the REFERENCE'S OWN device code: lib/ransac_voting_gpu_layer/src/ransac_voting_kernel.cu
+(generate_hypothesis_kernel :11-49, voting_for_hypothesis_kernel :88-126) compiled for gfx950 from the reference
+tree by `make -C oracle ref` (oracle/_ref/, git-ignored, travels with the tree to the GPU box) and run on the
+MI355X next to our kernels on identical device buffers.
+
+This pins the chain: reference kernels == plain-C restatement == numpy float32 oracle == HIP literal mode, all
+bit-exact; the default fast mode is then measured against the reference kernels' inlier sets."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref, refkernels
+from oracle import ransac_voting_oracle as O
+from pvnet_amd import synth, voting
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not refkernels.available("off"),
+                                 reason="oracle/_ref not built (needs the reference tree: make -C oracle ref)")]
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def compacted(first=600, h=120, w=160, radius=16, noise=True):
+    mask, planar, kpts = synth.make_batch(1, first_index=first, h=h, w=w, radius=radius, noise=noise,
+                                          background="normal")
+    vnp = synth.planar_to_vertex_view(planar)
+    coords, direct = O.compact(O.foreground(mask[0]), vnp[0])
+    return mask, planar, coords.astype(np.float32), np.ascontiguousarray(direct, np.float32)
+
+
+def test_reference_kernels_equal_c_restatement_and_our_ops():
+    _, _, coords, direct = compacted()
+    tn = coords.shape[0]
+    hn = 96
+    idxs = np.random.default_rng(3).integers(0, tn, (hn, 9, 2), dtype=np.int32)
+    idxs[0, 0] = [5, 5]           # the same pixel twice: the kernel returns early, the zero-filled output stays (:42-43)
+    idxs[1, 1] = [7, 7]
+    direct[9, 2] = direct[11, 2]  # parallel directions at different pixels: determinant exactly zero
+    idxs[2, 2] = [9, 11]
+    d, c, i = (torch.from_numpy(x).to(dev()) for x in (direct, coords, idxs))
+    hyp_ref = refkernels.generate_hypothesis(d, c, i)
+    assert hyp_ref[0, 0].abs().sum() == 0 and hyp_ref[2, 2].abs().sum() == 0
+    hyp_c = cref.generate_hypothesis(direct, coords, idxs)
+    assert hyp_ref.cpu().numpy().tobytes() == hyp_c.tobytes(), "C restatement != reference device code"
+    assert voting.generate_hypothesis(d, c, i).cpu().numpy().tobytes() == hyp_c.tobytes()
+    for thresh in (0.99, 0.999):
+        inl_ref = refkernels.voting_for_hypothesis(d, c, hyp_ref, thresh)
+        inl_c = np.zeros((hn, 9, tn), np.uint8)
+        cref.voting_for_hypothesis(direct, coords, hyp_c, inl_c, thresh)
+        np.testing.assert_array_equal(inl_ref.cpu().numpy(), inl_c)
+        ours = torch.zeros((hn, 9, tn), dtype=torch.uint8, device=dev())
+        voting.voting_for_hypothesis(d, c, hyp_ref, ours, thresh)
+        assert torch.equal(ours, inl_ref)
+        assert 0 < int(inl_ref.sum()) < hn * 9 * tn
+    # degenerate inputs of the voting kernel: zero direction (norm1 < 1e-6) and hypothesis on the pixel (norm2 < 1e-6)
+    direct2 = direct.copy()
+    direct2[4] = 0.0
+    hyp2 = hyp_c.copy()
+    hyp2[3, :, :] = coords[6]
+    d2, h2 = torch.from_numpy(direct2).to(dev()), torch.from_numpy(hyp2).to(dev())
+    inl_ref = refkernels.voting_for_hypothesis(d2, c, h2, 0.99)
+    assert int(inl_ref[:, :, 4].sum()) == 0 and int(inl_ref[3, :, 6].sum()) == 0
+    ours = torch.zeros_like(inl_ref)
+    voting.voting_for_hypothesis(d2, c, h2, ours, 0.99)
+    assert torch.equal(ours, inl_ref)
+
+
+@pytest.mark.parametrize("hn,thresh", [(128, 0.99), (256, 0.999)])
+def test_literal_path_equals_reference_device_code(hn, thresh):
+    """Whole batched path in literal mode vs the reference kernels applied to the path's own compacted pixels:
+    hypotheses bit-exact, inlier counts and winners exact."""
+    mask, planar, _ = synth.make_batch(3, first_index=700 + hn, h=200, w=260, radius=20, noise=True,
+                                       background="normal")
+    m = torch.from_numpy(mask).to(dev())
+    v = synth.planar_to_vertex_view(torch.from_numpy(planar).to(dev()))
+    seed = 11
+    out, dbg = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, seed=seed, literal=True,
+                                             return_debug=True)
+    for bi in range(3):
+        tn = int(dbg["tn"][bi])
+        rec = dbg["rec"][bi, :, :tn]                                  # [vn,tn,4] = (x, y, ux, uy) in literal mode
+        coords = rec[0, :, 0:2].contiguous()                          # [tn,2] (x, y) as torch.nonzero()[:, [1,0]] (:542-543)
+        direct = rec[:, :, 2:4].permute(1, 0, 2).contiguous()         # [tn,vn,2]
+        idxs = torch.from_numpy(O.draw_idxs(seed, bi, hn, 9, tn)).to(dev())
+        hyp_ref = refkernels.generate_hypothesis(direct, coords, idxs)            # [hn,vn,2]
+        ours = dbg["hyp"][bi].permute(1, 0, 2).contiguous()
+        assert ours.cpu().numpy().tobytes() == hyp_ref.cpu().numpy().tobytes()
+        inl = refkernels.voting_for_hypothesis(direct, coords, hyp_ref, thresh)   # [hn,vn,tn]
+        counts_ref = inl.sum(2, dtype=torch.int32)                                # :557
+        assert torch.equal(dbg["counts"][bi].T.contiguous(), counts_ref)
+        win_cnt, win_idx = torch.max(counts_ref, 0)                               # :558 (first maximum, as torch.max does on CPU)
+        first = (counts_ref == win_cnt[None]).int().argmax(0)
+        assert torch.equal(dbg["win"][bi, :, 0].long(), first)
+        assert torch.equal(dbg["win"][bi, :, 1], win_cnt)
+        # refinement (:579-594): inliers of the winner by the reference kernel, normal equations in float64
+        wp = hyp_ref[first, torch.arange(9, device=dev())][None].contiguous()     # [1,vn,2]
+        win_inl = refkernels.voting_for_hypothesis(direct, coords, wp, thresh)[0].double()  # [vn,tn]
+        normal = torch.stack([direct[:, :, 1], -direct[:, :, 0]], 2).permute(1, 0, 2).double() * win_inl[:, :, None]
+        bvec = (normal * coords.double()[None]).sum(2)
+        ata = normal.transpose(1, 2) @ normal
+        atb = (normal * bvec[:, :, None]).sum(1)
+        ref_pts = torch.linalg.solve(ata, atb[:, :, None])[:, :, 0]
+        assert (out[bi].double() - ref_pts).abs().max() < 1e-3
+
+
+def test_fast_mode_against_reference_inlier_sets():
+    """Default (fast) mode: its vote counts differ from the reference kernels' on a tiny fraction of
+    (hypothesis, pixel) pairs only -- those within rounding of the threshold -- and its winners carry the same counts
+    to within that."""
+    mask, planar, _ = synth.make_batch(2, first_index=820, h=240, w=320, radius=24, noise=True, background="normal")
+    m = torch.from_numpy(mask).to(dev())
+    v = synth.planar_to_vertex_view(torch.from_numpy(planar).to(dev()))
+    hn, thresh, seed = 256, 0.99, 5
+    _, lit = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, seed=seed, literal=True, return_debug=True)
+    lit_counts = lit["counts"].clone()
+    lit_hyp = lit["hyp"].clone()
+    _, fast = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, seed=seed, return_debug=True)
+    assert fast["hyp"].cpu().numpy().tobytes() == lit_hyp.cpu().numpy().tobytes()  # hypotheses do not depend on the mode
+    diff = (fast["counts"] - lit_counts).abs()
+    tn = fast["tn"][:2].sum().item()
+    assert diff.sum().item() <= 2e-6 * hn * 9 * tn + 2  # pair tests decided differently: ~1e-7 of them
+    assert diff.max().item() <= 2
+
+
+@pytest.mark.skipif(not refkernels.available("fast"), reason="fma build of the reference kernels absent")
+def test_fma_contraction_moves_the_reference_itself():
+    """nvcc (--fmad=true) and hipcc both contract a*b+c by default, so the reference's own binaries differ from the
+    one-rounding-per-operation reading of its source: hypotheses by a few ulp, inlier flags on ~1e-6 of the pairs.
+    That is the reference's own noise floor; our tolerance (1e-3 px) and the literal mode sit inside it."""
+    _, _, coords, direct = compacted(first=610, h=200, w=260, radius=22)
+    tn = coords.shape[0]
+    hn = 256
+    idxs = np.random.default_rng(9).integers(0, tn, (hn, 9, 2), dtype=np.int32)
+    d, c, i = (torch.from_numpy(x).to(dev()) for x in (direct, coords, idxs))
+    h_off = refkernels.generate_hypothesis(d, c, i, contract="off")
+    h_fma = refkernels.generate_hypothesis(d, c, i, contract="fast")
+    rel = ((h_off - h_fma).abs() / h_off.abs().clamp_min(1.0)).max().item()
+    assert rel < 1e-2  # ill-conditioned intersections (near-parallel lines) amplify the last-bit differences
+    i_off = refkernels.voting_for_hypothesis(d, c, h_off, 0.99, contract="off")
+    i_fma = refkernels.voting_for_hypothesis(d, c, h_off, 0.99, contract="fast")
+    flips = (i_off != i_fma).float().mean().item()
+    assert flips < 1e-4
