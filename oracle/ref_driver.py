@@ -96,3 +96,19 @@ def run_v3(mask: np.ndarray, vertex: np.ndarray, hn: int, *, torch_seed: int = 0
         out = ref.ransac_voting_layer_v3(torch.from_numpy(np.ascontiguousarray(mask)),
                                          torch.from_numpy(np.ascontiguousarray(vertex)), hn, **kw)
     return out.numpy().astype(np.float32), cap
+
+
+def run(fn_name: str, mask: np.ndarray, vertex: np.ndarray, *args, torch_seed: int = 0, **kw):
+    """Any of the driver's sibling functions (ransac_voting_layer_v5, estimate_voting_distribution_with_mean,
+    ransac_motion_voting, generate_hypothesis, ...) on numpy inputs -> (tuple of numpy outputs, Capture).
+    numpy positional arguments after ``vertex`` (e.g. ``mean``) are converted to tensors."""
+    import torch
+    cap = Capture()
+    with reference_driver(cap) as ref:
+        torch.manual_seed(torch_seed)
+        targs = [torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a for a in args]
+        out = getattr(ref, fn_name)(torch.from_numpy(np.ascontiguousarray(mask)),
+                                    torch.from_numpy(np.ascontiguousarray(vertex)), *targs, **kw)
+    if not isinstance(out, (tuple, list)):
+        out = (out,)
+    return tuple(o.numpy() for o in out), cap

@@ -11,6 +11,9 @@ G6  ref_driver_v3.npz -- outputs of the REFERENCE'S OWN ransac_voting_layer_v3 (
                       restatement, which tests/test_reference_kernels.py holds bit-equal to the reference's device code),
                       together with what the run drew: the idxs of every live image, the pixels it kept, the rounds its
                       confidence loop made.  Inputs are regenerated from the recorded synth parameters.
+G7  ref_driver_siblings.npz -- the same for the reference's sibling functions of the "next" rows of SURVEY section 8(f):
+                      ransac_voting_layer_v5 (:763-858), estimate_voting_distribution_with_mean (:333-406),
+                      ransac_motion_voting (:960-981) and the Python-level generate_hypothesis (:983-1034).
 G3  noisy_oracle.npz -- float64-oracle outputs (key-points, winner indices, winner counts) on seeded noisy
                       synthetic images with the counter-based RNG; guards the oracle itself against drift.
 """
@@ -114,10 +117,49 @@ def make_ref_driver():
     np.savez_compressed(os.path.join(OUT, "ref_driver_v3.npz"), **flat)
 
 
+SIBLING_CASE = dict(b=2, first_index=950, h=96, w=128, radius=13, noise=True, edit="none")
+
+
+def keep_from_capture(cap, live, shape):
+    keep = np.zeros(shape, bool)
+    for j, bi in enumerate(live):
+        xy = cap.coords[j].astype(np.int64)
+        keep[bi, xy[:, 1], xy[:, 0]] = True
+    return keep
+
+
+def make_ref_siblings():
+    from oracle import ref_driver
+    mask, vertex, kpts = ref_driver_inputs(SIBLING_CASE)
+    b = mask.shape[0]
+    flat = {}
+    # v5: default max_num=100 -> every image is thinned; returns (points, confidence at 0.999)
+    (pts, conf), cap = ref_driver.run("ransac_voting_layer_v5", mask, vertex, 64, torch_seed=7, inlier_thresh=0.99)
+    flat.update(v5_pts=pts, v5_conf=conf, v5_keep_bits=np.packbits(keep_from_capture(cap, range(b), mask.shape)),
+                v5_idxs=np.stack(cap.idxs).astype(np.int32), v5_tn=np.array(cap.tn))
+    # distribution about the true key-points: 4 rounds of 64 hypotheses
+    mean = kpts.astype(np.float32)
+    (mean_out, cov), cap = ref_driver.run("estimate_voting_distribution_with_mean", mask, vertex, mean, torch_seed=8,
+                                          round_hyp_num=64, min_hyp_num=256, inlier_thresh=0.99)
+    rounds = len(cap.idxs) // b
+    idxs = np.stack([np.concatenate(cap.idxs[bi * rounds:(bi + 1) * rounds], 0) for bi in range(b)]).astype(np.int32)
+    flat.update(dist_mean=mean, dist_cov=cov, dist_idxs=idxs, dist_rounds=np.array(rounds))
+    # motion voting: no extension involved at all
+    (mv,), _ = ref_driver.run("ransac_motion_voting", mask, vertex)
+    flat.update(motion=mv)
+    # Python-level generate_hypothesis: all hypotheses and their inlier counts
+    (hyp, counts), cap = ref_driver.run("generate_hypothesis", mask, vertex, 48, torch_seed=9, inlier_thresh=0.99)
+    flat.update(gh_hyp=hyp, gh_counts=counts, gh_idxs=np.stack(cap.idxs).astype(np.int32))
+    np.savez_compressed(os.path.join(OUT, "ref_driver_siblings.npz"), **flat)
+    print("ref siblings: v5 tn", cap.tn, "conf", conf.round(3).tolist(), "| dist rounds", rounds,
+          "| cov[0,0]", cov[0, 0].round(4).tolist())
+
+
 if __name__ == "__main__":
     if os.path.isdir(REF):
         make_demo()
         make_ref_driver()
+        make_ref_siblings()
     else:
         print("no /root/reference: demo and reference-driver fixtures not regenerated")
     make_noisy()

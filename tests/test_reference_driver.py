@@ -87,3 +87,71 @@ def test_hip_path_reproduces_the_executed_reference_driver(ci, literal):
     v = torch.from_numpy(np.ascontiguousarray(vertex)).to(dev)
     out = voting.ransac_voting_layer_v3(m, v, case["hn"], idxs=torch.from_numpy(idxs).to(dev), literal=literal, **kw)
     assert np.abs(out.cpu().numpy() - ref_out).max() < TOL_REF_PX
+
+
+# ------------------------------------------------------------------------------------------------ G7: siblings
+SIB = np.load(os.path.join(HERE, "golden", "ref_driver_siblings.npz"))
+
+
+def sibling_inputs():
+    mask, vertex, kpts = MG.ref_driver_inputs(MG.SIBLING_CASE)
+    b, h, w = mask.shape
+    keep5 = np.unpackbits(SIB["v5_keep_bits"])[:b * h * w].reshape(b, h, w).astype(bool)
+    return mask, vertex, kpts, keep5
+
+
+def test_oracle_reproduces_reference_v5_distribution_motion_and_hypothesis_counts():
+    mask, vertex, kpts, keep5 = sibling_inputs()
+    b = mask.shape[0]
+    # v5 (:763-858): thinned to ~max_num=100 pixels by the reference's own draw; points and confidence at 0.999
+    assert (SIB["v5_tn"] < 160).all() and (SIB["v5_tn"] > 50).all()
+    pts = O.ransac_voting_layer_v3(mask * keep5, vertex, 64, inlier_thresh=0.99, idxs=SIB["v5_idxs"], dtype=np.float32)
+    assert np.abs(pts - SIB["v5_pts"]).max() < TOL_REF_PX
+    conf = O.vote_confidence(mask * keep5, vertex, SIB["v5_pts"], 0.999, dtype=np.float32)
+    assert np.abs(conf - SIB["v5_conf"]).max() < 1e-6
+    # distribution about a given mean (:333-406): 4 rounds of 64 independent pairs = one draw of 256
+    assert int(SIB["dist_rounds"]) == 4 and SIB["dist_idxs"].shape == (b, 256, 9, 2)
+    cov = O.estimate_voting_distribution_with_mean(mask, vertex, SIB["dist_mean"], 256, inlier_thresh=0.99,
+                                                   idxs=SIB["dist_idxs"], dtype=np.float32)
+    assert np.abs(cov - SIB["dist_cov"]).max() < 1e-3 * max(1.0, np.abs(SIB["dist_cov"]).max())
+    # motion voting (:960-981)
+    assert np.abs(O.ransac_motion_voting(mask, vertex) - SIB["motion"]).max() < 1e-3
+    # Python-level generate_hypothesis (:983-1034): every hypothesis and its inlier count
+    _, dbg = O.ransac_voting_layer_v3(mask, vertex, 48, inlier_thresh=0.99, idxs=SIB["gh_idxs"], dtype=np.float32,
+                                      return_debug=True)
+    for bi in range(b):
+        assert dbg[bi]["hyp"].astype(np.float32).tobytes() == SIB["gh_hyp"][bi].tobytes()
+        np.testing.assert_array_equal(dbg[bi]["counts"], SIB["gh_counts"][bi])
+
+
+@pytest.mark.gpu
+def test_hip_siblings_reproduce_the_executed_reference():
+    import torch
+    from pvnet_amd import voting
+    mask, vertex, kpts, keep5 = sibling_inputs()
+    b = mask.shape[0]
+    dev = torch.device("cuda:0")
+    v = torch.from_numpy(np.ascontiguousarray(vertex)).to(dev)
+    m = torch.from_numpy(mask).to(dev)
+    m5 = torch.from_numpy(mask * keep5).to(dev)
+    for literal in (False, True):
+        pts, conf = voting.ransac_voting_layer_v5(m5, v, 64, inlier_thresh=0.99, max_num=30000, literal=literal,
+                                                  idxs=torch.from_numpy(SIB["v5_idxs"]).to(dev))
+        assert np.abs(pts.cpu().numpy() - SIB["v5_pts"]).max() < TOL_REF_PX
+        # the confidence is evaluated at OUR refined point (<= 1e-3 px from the reference's): a pixel or two of the
+        # ~100 may sit within that of the 0.999 cone's edge
+        assert np.abs(conf.cpu().numpy() - SIB["v5_conf"]).max() <= 2.0 / SIB["v5_tn"].min() + 1e-6
+        mean = torch.from_numpy(SIB["dist_mean"]).to(dev)
+        _, cov = voting.estimate_voting_distribution_with_mean(m, v, mean, round_hyp_num=64, min_hyp_num=256,
+                                                               inlier_thresh=0.99, literal=literal,
+                                                               idxs=torch.from_numpy(SIB["dist_idxs"]).to(dev))
+        tol = (1e-3 if literal else 2e-2) * max(1.0, np.abs(SIB["dist_cov"]).max())  # fast mode: +-1 votes move ratios
+        assert np.abs(cov.cpu().numpy() - SIB["dist_cov"]).max() < tol
+        hyp, counts = voting.generate_hypothesis_counts(m, v, 48, inlier_thresh=0.99, literal=literal,
+                                                        idxs=torch.from_numpy(SIB["gh_idxs"]).to(dev))
+        assert hyp.cpu().numpy().tobytes() == SIB["gh_hyp"].tobytes()
+        if literal:
+            np.testing.assert_array_equal(counts.cpu().numpy(), SIB["gh_counts"])
+        else:
+            assert np.abs(counts.cpu().numpy() - SIB["gh_counts"]).max() <= 1
+    assert np.abs(voting.ransac_motion_voting(m, v).cpu().numpy() - SIB["motion"]).max() < 1e-3
