@@ -11,10 +11,13 @@ batch of 32 synthetic images per GPU, inputs resident in HBM.  With N > 1 every 
 all-gather of the [32, 9, 2] key-points.  Rank 0 prints ONE JSON line.
 
 Besides the contract's fields the line carries
-  roofline      the dominant kernel (inlier scoring).  It is fp32-VALU bound, not HBM bound, so
-                `achieved` is algorithmic TFLOP/s (12 flop x hn*vn*tn pair tests) against the
-                157.3 TFLOP/s fp32 vector peak (= the dense f32 MFMA rate on gfx950); duration measured live
-                with hipEvents on the op's stream (pvnet_vote_v3_profiled).
+  roofline      the dominant kernel (inlier scoring), compute bound, not HBM bound.  It runs the
+                vote's two 3-term fp32 dot products as bf16x3 MFMAs (v_mfma_f32_32x32x16_bf16, fp32 accumulate):
+                `achieved` = the matrix flops executed for the algorithmic hn*vn*tn pair tests (2 MFMAs per
+                32x32 tests = 64 flop per test) over the kernel's duration, `peak` = 2.5 PFLOP/s dense bf16;
+                `algorithmic` restates it with SURVEY.md 8d's 12 fp32 flop per test against the 157.3 TFLOP/s
+                fp32 vector peak, `issue_bound` against what the SIMD can issue (64 MFMA + 64 VALU cycles per
+                1024 tests).  Duration measured live with hipEvents on the op's stream (pvnet_vote_v3_profiled).
   roofline_hbm  the whole path against the HBM roofline: algorithmic bytes (24 576 072 B per voting with the
                 int64 mask) x votings / time of all seven launches, peak 8 TB/s.
   cpu_baseline  the plain-C restatement (oracle, OpenMP over all host cores) timed on a bounded sample.
@@ -41,6 +44,11 @@ BYTES_PER_VOTING = H * W * 8 + H * W * VN * 2 * 4 + VN * 2 * 4  # 24 576 072 (SU
 FLOP_PER_PAIR = 12
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = f32 MFMA dense peak
+PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16: 32 cycles per SIMD)
+MFMA_FLOP_PER_PAIR = 2 * (2 * 32 * 32 * 16) / (32 * 32)  # two 32x32x16 MFMAs (cr, dt) per 32x32 pair tests = 64
+ISSUE_CYCLES_PER_1024 = 2 * 32 + 32 * 2  # 2 MFMAs x 32 cycles + 32 VALU (2 per test per lane) x 2 cycles, per SIMD
+PEAK_CLOCK_HZ = 2.4e9
+N_SIMD = 256 * 4
 
 
 def parse():
@@ -219,20 +227,29 @@ def main():
             "metric": "RANSAC votings/s (480x640, 9 kpts, batch 32) + HBM GB/s vs roofline",
             "value": votings_per_s, "unit": "votings/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16x3 products, f32 accumulate (f32-equivalent; refinement f64)", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[2]: batch=32 synthetic 480x640 fields per GPU, 9 keypoints, "
                                    "1024 hypotheses, inlier_thresh 0.99, int64 mask, planar strided field",
                        "batch_per_gpu": BATCH, "global_batch": world * BATCH, "h": H, "w": W, "vn": VN, "hn": HN,
                        "mask_radius": a.radius, "mean_foreground_px": tn_per_batch / BATCH,
                        "field": "clean" if a.clean else "noisy (0.05 rad + 10% outliers), N(0,1) background",
                        "input_sets_cycled": len(sets), "parallelism": f"images sharded over {world} GPU(s)"},
-            "roofline": {"kernel": "score_kernel", "bound": "valu", "achieved": FLOP_PER_PAIR * pairs / score_s / 1e12,
-                         "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": FLOP_PER_PAIR * pairs / score_s / 1e12 / PEAK_F32_TFLOPS,
-                         "traffic": measured_traffic("score_kernel"),
+            "roofline": {"kernel": "score_mfma_kernel", "bound": "mfma",
+                         "achieved": MFMA_FLOP_PER_PAIR * pairs / score_s / 1e12, "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": MFMA_FLOP_PER_PAIR * pairs / score_s / 1e12 / PEAK_BF16_TFLOPS,
+                         "traffic": measured_traffic("score_mfma_kernel"),
                          "avg_launch_ms": stage_ms["score"], "pair_tests_per_launch": pairs,
-                         "note": "fp32 vector peak = dense f32 MFMA rate on gfx950; no MFMA used (irregular "
-                                 "gather/reduce); 12 flop per pair test as SURVEY.md 8d counts them"},
+                         "flop_per_pair_executed": MFMA_FLOP_PER_PAIR,
+                         "algorithmic": {"flop_per_pair": FLOP_PER_PAIR,
+                                         "tflops": FLOP_PER_PAIR * pairs / score_s / 1e12,
+                                         "vs_fp32_vector_peak": FLOP_PER_PAIR * pairs / score_s / 1e12 / PEAK_F32_TFLOPS},
+                         "issue_bound": {"cycles_per_1024_pairs_per_simd": ISSUE_CYCLES_PER_1024,
+                                         "pairs_per_s": 1024 / ISSUE_CYCLES_PER_1024 * PEAK_CLOCK_HZ * N_SIMD,
+                                         "frac": pairs / score_s / (1024 / ISSUE_CYCLES_PER_1024 * PEAK_CLOCK_HZ * N_SIMD)},
+                         "note": "each pair test = two 3-term fp32 dot products + compare; operands split into three "
+                                 "bf16 parts, six part products kept per product (K = 15 of 16), fp32 accumulation on "
+                                 "the matrix pipe; 2 VALU ops per test count the votes.  Matrix and vector issue do "
+                                 "not overlap within a SIMD for this mix (tools/ubench_mfma.hip), hence issue_bound"},
             "roofline_hbm": {"bound": "hbm", "achieved": BYTES_PER_VOTING * BATCH / path_s / 1e9,
                              "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": BYTES_PER_VOTING * BATCH / path_s / 1e9 / PEAK_HBM_GBS,

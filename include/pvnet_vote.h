@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVNET_VOTE_ABI_VERSION 1
+#define PVNET_VOTE_ABI_VERSION 2
 
 /* negative library error codes */
 #define PVNET_E_BADARG      (-1)   /* null pointer / non-positive size / unsupported dtype or stride */
@@ -75,10 +75,11 @@ typedef struct PvnetVoteLayout {
     size_t off_win;         /* int32  [b][vn][2]           (winner index, winner count)                     */
     size_t off_seg;         /* int32  [2][b][nseg]         foreground count of every 4096-pixel segment     */
     size_t off_items;       /* int32x4 [max items]         scoring work items (image, kp, chunk group, slice) */
+    size_t off_hypb;        /* uint4  [b][vn][hn_pad][2]   fast mode: hypotheses as bf16x3 MFMA B operands         */
     size_t total_bytes;
     int32_t nseg;           /* ceil(words / 64)                                                             */
     int32_t wg_g, wg_s;     /* a scoring workgroup covers wg_g hypothesis groups x wg_s chunks (wg_g*wg_s=4) */
-    int32_t reserved_;
+    int32_t reserved_;      /* 1: fast mode scores on the matrix pipe (score_mfma_kernel), 0: VALU kernel                */
 } PvnetVoteLayout;
 
 /* Host-only: fills *out for a problem size.  max_num as passed to pvnet_vote_v3. */

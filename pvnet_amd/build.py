@@ -29,6 +29,7 @@ def hipcc_path() -> str:
 def flags():
     return ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared", "-fno-fast-math",
             "-fno-slp-vectorize",  # keep the scoring loops as scalar v_sub/v_mul/v_fma (packed f32 gains nothing on gfx950)
+            "-mllvm", "-amdgpu-mfma-vgpr-form",  # MFMA results straight into VGPRs: the vote's v_cmp reads them in place
             "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-Wall"]
 
 

@@ -63,7 +63,7 @@ struct VoteParams {
     int mask_dtype, mask_linear, num_classes;
     const float* vertex;
     int64_t vs0, vs1, vs2, vs3, vs4;
-    int b, h, w, vn, hn, npix, words, cap, chunk, max_chunks, hpl, hgroups, hn_pad, wg_g, wg_s;
+    int b, h, w, vn, hn, npix, words, cap, chunk, max_chunks, hpl, hgroups, hn_pad, wg_g, wg_s, mode;
     float thresh, tau;
     int min_num, max_num;
     uint64_t seed;
@@ -79,6 +79,7 @@ struct VoteParams {
     int32_t* pix;
     float4* rec;
     float2* hyp;
+    uint4* hypb;      // fast mode: the same hypotheses as bf16x3 B operands of the scoring MFMAs, [b][vn][hn_pad][2]
     uint16_t* partial;
     int32_t* counts;
     int32_t* win;
@@ -155,6 +156,46 @@ __device__ __forceinline__ float vote_expanded(float4 a, float2 b, float hx, flo
     const float cr = fmaf(hx, a.x, fmaf(hy, a.y, a.z));
     const float t = b.y - fabsf(cr);
     return __builtin_amdgcn_fmed3f(fmaf(hx, a.w, fmaf(hy, b.x, t)), 0.f, 1.f);  // clamp folds into the fma
+}
+
+// ---- bf16x3 operands of the matrix-pipe scoring kernel ------------------------------------------------------
+// An fp32 value is the exact sum of three bf16 parts (round-to-nearest each time).  A product x*a keeps the six
+// part pairs of relative weight >= 2^-16 (x0a0 x0a1 x1a0 x0a2 x2a0 x1a1; the dropped three are below one fp32
+// rounding of the product), so the 3-term dot products of the vote, cr = hx*a + hy*b + c and dt = hx*e + hy*f + g,
+// are ONE v_mfma_f32_32x32x16_bf16 each (K = 6 + 6 + 3, one slot spare), accumulated in fp32 by the matrix pipe:
+//   A row (pixel)      k = 0..15 : a0 a1 a0 a2 a0 a1 | b0 b1 b0 b2 b0 b1 | c0 c1 c2 0
+//   B column (hyp.)    k = 0..15 : x0 x0 x1 x0 x2 x1 | y0 y0 y1 y0 y2 y1 | 1  1  1  0
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void split3(float x, uint32_t& p0, uint32_t& p1, uint32_t& p2) {  // raw bf16 bits
+    const __bf16 h0 = (__bf16)x;
+    const float r1 = x - (float)h0;
+    const __bf16 h1 = (__bf16)r1;
+    const float r2 = r1 - (float)h1;
+    const __bf16 h2 = (__bf16)r2;
+    p0 = __builtin_bit_cast(unsigned short, h0);
+    p1 = __builtin_bit_cast(unsigned short, h1);
+    p2 = __builtin_bit_cast(unsigned short, h2);
+}
+__device__ __forceinline__ uint32_t pk(uint32_t lo, uint32_t hi) { return lo | (hi << 16); }
+// the 16 K-slots of one operand row: (u, v, w) -> u0 u1 u0 u2 u0 u1 | v0 v1 v0 v2 v0 v1 | w0 w1 w2 0
+__device__ __forceinline__ void a_row(float u, float v, float w, uint4& lo, uint4& hi) {
+    uint32_t u0, u1, u2, v0, v1, v2, w0, w1, w2;
+    split3(u, u0, u1, u2);
+    split3(v, v0, v1, v2);
+    split3(w, w0, w1, w2);
+    lo = make_uint4(pk(u0, u1), pk(u0, u2), pk(u0, u1), pk(v0, v1));
+    hi = make_uint4(pk(v0, v2), pk(v0, v1), pk(w0, w1), pk(w2, 0u));
+}
+// the hypothesis side: (x, y) -> x0 x0 x1 x0 x2 x1 | y0 y0 y1 y0 y2 y1 | 1 1 1 0
+__device__ __forceinline__ void b_col(float x, float y, uint4& lo, uint4& hi) {
+    uint32_t x0, x1, x2, y0, y1, y2;
+    split3(x, x0, x1, x2);
+    split3(y, y0, y1, y2);
+    const uint32_t one = 0x3F80u;
+    lo = make_uint4(pk(x0, x0), pk(x1, x0), pk(x2, x1), pk(y0, y0));
+    hi = make_uint4(pk(y1, y0), pk(y2, y1), pk(one, one), pk(one, 0u));
 }
 
 __device__ __forceinline__ int wave_reduce_add(int v) {
@@ -492,6 +533,19 @@ __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
         hyp_intersect(d0.x, d0.y, q0.x, q0.y, d1.x, d1.y, q1.x, q1.y, hx, hy);
     }
     P.hyp[((size_t)bi * P.vn + k) * P.hn_pad + h] = make_float2(hx, hy);
+    if (!LITERAL && P.mode) {  // the same hypothesis about the image's local origin, as a bf16x3 B operand column
+        float ox = 0.f, oy = 0.f;
+        if (live) {
+            const int pm = P.pix[(size_t)bi * P.cap + tn / 2];  // the origin plan_image() records for this image
+            ox = (float)(pm % P.w);
+            oy = (float)(pm / P.w);
+        }
+        uint4 lo, hi;
+        b_col(hx - ox, hy - oy, lo, hi);
+        uint4* o = P.hypb + (((size_t)bi * P.vn + k) * P.hn_pad + h) * 2;
+        o[0] = lo;
+        o[1] = hi;
+    }
     }
 }
 
@@ -595,6 +649,127 @@ __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// K4 (fast mode): matrix-pipe scoring.  A work item = (image, key-point, pixel group of wg_s chunks, slice of
+// 4 * MH * 32 hypotheses).  The workgroup turns the group's records into bf16x3 A rows in LDS (32-pixel tiles,
+// A_cr | A_dt); each of its 4 waves keeps the B columns of MH * 32 hypotheses in registers (written by K3) and, per
+// tile, issues 2 MFMAs per 32 hypotheses: cr and dt of 32 x 32 (pixel, hypothesis) pairs land in the lane that
+// owns the hypothesis (column = lane & 31, 16 rows per lane), so the vote is v_cmp(dt > |cr|) + add-with-carry:
+// 2 VALU operations per test instead of 6, the other four run on the matrix pipe at bf16 rate.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int TILE_U4 = 128;  // uint4 per 32-pixel tile: A_cr rows (32 x 2) then A_dt rows (32 x 2)
+
+// Eight votes of the lane's hypothesis: cnt += (dt > |cr|) for eight (dt, cr) pairs, 2 VALU operations per test.
+// Hand-placed so that every SGPR mask is consumed >= 3 instructions after the compare that wrote it (the
+// "VALU writes SGPR -> VALU reads it" hazard of gfx940+ costs hipcc an s_nop per pair otherwise).
+__device__ __forceinline__ void vote8(int& cnt, float d0, float c0, float d1, float c1, float d2, float c2, float d3,
+                                      float c3, float d4, float c4, float d5, float c5, float d6, float c6, float d7,
+                                      float c7) {
+    unsigned long long m0, m1, m2, m3;
+    int x, y;
+    asm volatile(
+        "v_cmp_gt_f32_e64 %1, %7, |%8|\n"
+        "v_cmp_gt_f32_e64 %2, %9, |%10|\n"
+        "v_cmp_gt_f32_e64 %3, %11, |%12|\n"
+        "v_cmp_gt_f32_e64 %4, %13, |%14|\n"
+        "v_cndmask_b32_e64 %5, 0, 1, %1\n"
+        "v_cmp_gt_f32_e64 %1, %15, |%16|\n"
+        "v_addc_co_u32_e64 %0, %2, %0, %5, %2\n"
+        "v_cndmask_b32_e64 %6, 0, 1, %3\n"
+        "v_cmp_gt_f32_e64 %2, %17, |%18|\n"
+        "v_addc_co_u32_e64 %0, %4, %0, %6, %4\n"
+        "v_cmp_gt_f32_e64 %3, %19, |%20|\n"
+        "v_cmp_gt_f32_e64 %4, %21, |%22|\n"
+        "v_cndmask_b32_e64 %5, 0, 1, %1\n"
+        "v_cndmask_b32_e64 %6, 0, 1, %3\n"
+        "v_addc_co_u32_e64 %0, %2, %0, %5, %2\n"
+        "v_addc_co_u32_e64 %0, %4, %0, %6, %4\n"
+        : "+v"(cnt), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&v"(x), "=&v"(y)
+        : "v"(d0), "v"(c0), "v"(d1), "v"(c1), "v"(d2), "v"(c2), "v"(d3), "v"(c3), "v"(d4), "v"(c4), "v"(d5), "v"(c5),
+          "v"(d6), "v"(c6), "v"(d7), "v"(c7));
+}
+
+template <int MH>
+__global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* s_t = reinterpret_cast<uint4*>(smem);
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int npx = P.wg_s * P.chunk, ntiles = npx >> 5;
+    const int32_t* __restrict__ ctrl = P.ctrl;
+    const int total = ctrl[P.b * CTRL_STRIDE];
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint4* lbase = s_t + col * 2 + half;  // this lane's 16 bytes of every A row block
+
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+        const int4 desc = P.items[item];  // (image, key-point, chunk group, hypothesis slice), planned by K3
+        const int bi = desc.x, k = desc.y, cg = desc.z, hq = desc.w;
+        const int tn = ctrl[bi * CTRL_STRIDE + C_TN];
+        const float ox = (float)ctrl[bi * CTRL_STRIDE + C_OX], oy = (float)ctrl[bi * CTRL_STRIDE + C_OY];
+        const size_t bk = (size_t)bi * P.vn + k;
+        const int tpad = (tn + PAD - 1) / PAD * PAD;
+        const int h0 = hq * 4 * MH * 32 + wave * MH * 32;  // this wave's first hypothesis
+
+        bf16x8 B[MH];
+#pragma unroll
+        for (int t = 0; t < MH; ++t) {
+            const uint4 raw = P.hypb[(bk * P.hn_pad + h0 + t * 32 + col) * 2 + half];
+            B[t] = __builtin_bit_cast(bf16x8, raw);
+        }
+        __syncthreads();  // the previous item's tiles have been consumed
+        for (int i = threadIdx.x; i < npx; i += 256) {  // thread = pixel: expand its record once per workgroup
+            const int p = cg * npx + i;
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < tpad) q = P.rec[bk * P.cap + p];
+            float4 a;
+            float2 b;
+            make_pixrec(q, P.tau, ox, oy, a, b);  // a = (My, -Mx, -Ec, Tx), b = (Ty, -Ed); zero record -> zero rows
+            uint4* t = s_t + (i >> 5) * TILE_U4 + (i & 31) * 2;
+            a_row(a.x, a.y, a.z, t[0], t[1]);
+            a_row(a.w, b.x, b.y, t[64], t[65]);
+        }
+        __syncthreads();
+
+        int cnt[MH];
+#pragma unroll
+        for (int t = 0; t < MH; ++t) cnt[t] = 0;
+        // Flat software pipeline over (pixel tile, hypothesis tile) steps: the two MFMAs of step i+1 are issued
+        // around the votes of step i (half of them behind each), on ping-pong accumulators.
+        bf16x8 Acr = __builtin_bit_cast(bf16x8, lbase[0]), Adt = __builtin_bit_cast(bf16x8, lbase[64]);
+        f32x16 cr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Acr, B[0], zero, 0, 0, 0);
+        f32x16 dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Adt, B[0], zero, 0, 0, 0);
+        for (int tile = 0; tile < ntiles; ++tile) {
+            const int nt = tile + 1 < ntiles ? tile + 1 : tile;  // (after the last tile: a harmless repeat)
+            const bf16x8 Ncr = __builtin_bit_cast(bf16x8, lbase[nt * TILE_U4]);
+            const bf16x8 Ndt = __builtin_bit_cast(bf16x8, lbase[nt * TILE_U4 + 64]);
+#pragma unroll
+            for (int t = 0; t < MH; ++t) {
+                const f32x16 cr2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Acr : Ncr, B[(t + 1) % MH], zero, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                vote8(cnt[t], dt[0], cr[0], dt[1], cr[1], dt[2], cr[2], dt[3], cr[3], dt[4], cr[4], dt[5], cr[5], dt[6],
+                      cr[6], dt[7], cr[7]);
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x16 dt2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Adt : Ndt, B[(t + 1) % MH], zero, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                vote8(cnt[t], dt[8], cr[8], dt[9], cr[9], dt[10], cr[10], dt[11], cr[11], dt[12], cr[12], dt[13], cr[13],
+                      dt[14], cr[14], dt[15], cr[15]);
+                __builtin_amdgcn_sched_barrier(0);
+                cr = cr2;
+                dt = dt2;
+            }
+            Acr = Ncr;
+            Adt = Ndt;
+        }
+        // the group's row of counts (uint16: <= wg_s * chunk votes); K5 sums one row per chunk GROUP in this mode
+        uint16_t* po = P.partial + (bk * P.max_chunks + cg) * P.hn_pad + h0;
+#pragma unroll
+        for (int t = 0; t < MH; ++t) {
+            const int c = cnt[t] + __shfl_xor(cnt[t], 32, 64);  // the half-waves hold different rows of the column
+            if (half == 0) po[t * 32 + col] = (uint16_t)c;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // K5: arg-max + least-squares refinement                        (ransac_voting_gpu.py:561-569, 579-595, 503-512)
 // ------------------------------------------------------------------------------------------------------------
 constexpr int RT = 512;  // threads per (image, key-point) (measured: 256 -> 19 us, 1024 -> 23 us at batch 32)
@@ -604,7 +779,9 @@ __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
     const int k = blockIdx.x, bi = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t bk = (size_t)bi * P.vn + k;
-    const int nch = P.ctrl[bi * CTRL_STRIDE + C_NCHUNKS];
+    const int nchunks = P.ctrl[bi * CTRL_STRIDE + C_NCHUNKS];
+    // rows of partial counts to sum: one per chunk, or one per chunk group when the matrix-pipe kernel scored
+    const int nch = (!LITERAL && P.mode) ? (nchunks + P.wg_s - 1) / P.wg_s : nchunks;
     int status = P.ctrl[bi * CTRL_STRIDE + C_STATUS];
 
     __shared__ unsigned long long s_best[RW];
@@ -945,12 +1122,24 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
     {   // K4: persistent grid, work items strided over its waves
         const long long max_items =
             (long long)P.b * P.vn * (P.hgroups / P.wg_g) * ((P.max_chunks + P.wg_s - 1) / P.wg_s);
-        const int wgs_per_cu = env_int("PVNET_SCORE_WGS_PER_CU", 8);
+        const int wgs_per_cu = env_int("PVNET_SCORE_WGS_PER_CU", (!literal && P.mode) ? 4 : 8);
         long long wgs = wgs_per_cu > 0 ? (long long)num_cus() * wgs_per_cu : max_items;  // 0: one workgroup per item
         if (wgs > max_items) wgs = max_items;
         if (wgs < 1) wgs = 1;
-        int rc = literal ? launch_score<true>(P, dim3((unsigned)wgs), s) : launch_score<false>(P, dim3((unsigned)wgs), s);
-        if (rc) return rc;
+        if (!literal && P.mode) {
+            const int mh = P.wg_g * P.hpl / 2;  // hypotheses per item = wg_g * 64 * hpl = 4 waves * mh * 32
+            const size_t lds = (size_t)(P.wg_s * P.chunk / 32) * TILE_U4 * sizeof(uint4);
+            switch (mh) {
+                case 1: hipLaunchKernelGGL(score_mfma_kernel<1>, dim3((unsigned)wgs), dim3(256), lds, s, P); break;
+                case 2: hipLaunchKernelGGL(score_mfma_kernel<2>, dim3((unsigned)wgs), dim3(256), lds, s, P); break;
+                case 4: hipLaunchKernelGGL(score_mfma_kernel<4>, dim3((unsigned)wgs), dim3(256), lds, s, P); break;
+                case 8: hipLaunchKernelGGL(score_mfma_kernel<8>, dim3((unsigned)wgs), dim3(256), lds, s, P); break;
+                default: return PVNET_E_UNSUPPORTED;
+            }
+        } else {
+            int rc = literal ? launch_score<true>(P, dim3((unsigned)wgs), s) : launch_score<false>(P, dim3((unsigned)wgs), s);
+            if (rc) return rc;
+        }
         PV_LAUNCH_CHECK();
         PV_HIP(mark(5));
     }
@@ -986,6 +1175,7 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     P.b = b; P.h = h; P.w = w; P.vn = vn; P.hn = hn; P.npix = h * w;
     P.words = L.words; P.cap = L.cap; P.chunk = L.chunk; P.max_chunks = L.max_chunks;
     P.hpl = L.hpl; P.hgroups = L.hgroups; P.hn_pad = L.hn_pad; P.wg_g = L.wg_g; P.wg_s = L.wg_s;
+    P.mode = L.reserved_;
     P.thresh = thresh;
     P.tau = (thresh > 0.f && thresh < 1.f) ? (float)(sqrt(1.0 - (double)thresh * thresh) / (double)thresh) : 0.f;
     P.min_num = min_num; P.max_num = max_num; P.seed = seed; P.image_base = image_base; P.idxs = idxs; P.flags = flags;
@@ -998,6 +1188,7 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     P.pix = reinterpret_cast<int32_t*>(base + L.off_pix);
     P.rec = reinterpret_cast<float4*>(base + L.off_rec);
     P.hyp = reinterpret_cast<float2*>(base + L.off_hyp);
+    P.hypb = reinterpret_cast<uint4*>(base + L.off_hypb);
     P.partial = reinterpret_cast<uint16_t*>(base + L.off_partial);
     P.counts = reinterpret_cast<int32_t*>(base + L.off_counts);
     P.win = reinterpret_cast<int32_t*>(base + L.off_win);
@@ -1026,18 +1217,21 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
         cap = c < npix ? c : npix;
     }
     cap = (cap + PAD - 1) / PAD * PAD + PAD;
-    int hpl = hn >= 768 ? 8 : (hn >= 384 ? 4 : (hn >= 128 ? 2 : 1));  // tuned at hn = 1024 (profiles/r01_tune13)
+    const int mode = env_int("PVNET_SCORE_MODE", 1);  // 1: matrix-pipe scoring in fast mode, 0: VALU scoring
+    int hpl = hn >= 768 ? 8 : (hn >= 384 ? 4 : (hn >= 128 || mode ? 2 : 1));  // tuned at hn = 1024 (profiles/r01_tune13)
     hpl = env_int("PVNET_SCORE_HPL", hpl);
     if (hpl != 1 && hpl != 2 && hpl != 4 && hpl != 8) return PVNET_E_UNSUPPORTED;
+    if (mode && hpl == 1) return PVNET_E_UNSUPPORTED;  // a matrix-pipe work item holds >= 128 hypotheses
     int hgroups = (hn + 64 * hpl - 1) / (64 * hpl);
     // a scoring workgroup (4 waves) covers wg_g hypothesis groups x wg_s chunks of one (image, key-point)
-    const int wg_g = hgroups >= 3 ? 4 : hgroups;
+    const int wg_g = mode ? (hgroups >= 2 ? 2 : 1) : (hgroups >= 3 ? 4 : hgroups);
     hgroups = (hgroups + wg_g - 1) / wg_g * wg_g;
 
     const long long units = (long long)b * vn * hgroups;
     int chunk = units >= 128 ? 128 : 64;
     chunk = env_int("PVNET_SCORE_CHUNK", chunk);
     if (chunk < PAD || chunk % PAD != 0 || chunk > 1024) return PVNET_E_UNSUPPORTED;  // LDS: 4 * 1024 * 32 B
+    if (mode && chunk % 32 != 0) return PVNET_E_UNSUPPORTED;  // whole 32-pixel MFMA tiles
     L->b = b; L->h = h; L->w = w; L->vn = vn; L->hn = hn;
     L->cap = (int)cap;
     L->words = (int)((npix + 63) / 64);
@@ -1048,7 +1242,7 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     L->hn_pad = hgroups * 64 * hpl;
     L->wg_g = wg_g;
     L->wg_s = 4 / wg_g;
-    L->reserved_ = 0;
+    L->reserved_ = mode ? 1 : 0;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     L->nseg = (L->words + SEG_WORDS - 1) / SEG_WORDS;
@@ -1060,6 +1254,7 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     L->off_pix = take(sizeof(int32_t) * (size_t)b * cap);
     L->off_rec = take(sizeof(float) * 4 * (size_t)b * vn * cap);
     L->off_hyp = take(sizeof(float) * 2 * (size_t)b * vn * L->hn_pad);
+    L->off_hypb = take(mode ? sizeof(uint4) * 2 * (size_t)b * vn * L->hn_pad : 0);
     L->off_partial = take(sizeof(uint16_t) * (size_t)b * vn * L->max_chunks * L->hn_pad);
     L->off_counts = take(sizeof(int32_t) * (size_t)b * vn * L->hn_pad);
     L->off_win = take(sizeof(int32_t) * 2 * (size_t)b * vn);

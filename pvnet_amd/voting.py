@@ -35,7 +35,8 @@ class Layout(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("b", "h", "w", "vn", "hn", "cap", "words", "chunk", "max_chunks", "hpl",
                                           "hgroups", "hn_pad")] + \
                [(n, C.c_size_t) for n in ("off_ctrl", "off_bits", "off_pix", "off_rec", "off_hyp",
-                                          "off_partial", "off_counts", "off_win", "off_seg", "off_items", "total_bytes")] + \
+                                          "off_partial", "off_counts", "off_win", "off_seg", "off_items", "off_hypb",
+                                          "total_bytes")] + \
                [("nseg", C.c_int32), ("wg_g", C.c_int32), ("wg_s", C.c_int32), ("reserved_", C.c_int32)]
 
 
@@ -76,7 +77,7 @@ def load_library() -> C.CDLL:
     lib.pvnet_vote_confidence.argtypes = [f32p, C.c_float, f32p, C.c_uint32] + ws_tail
     lib.pvnet_vote_distribution.restype = C.c_int
     lib.pvnet_vote_distribution.argtypes = [f32p, f32p] + ws_tail
-    if lib.pvnet_vote_abi_version() != 1:
+    if lib.pvnet_vote_abi_version() != 2:
         raise RuntimeError("pvnet_amd: libpvnet_vote.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib

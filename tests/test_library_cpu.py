@@ -26,7 +26,7 @@ def test_exports_every_declared_symbol(lib):
             "pvnet_vote_build_info"} <= names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/pvnet_vote.h but not exported"
-    assert lib.pvnet_vote_abi_version() == 1
+    assert lib.pvnet_vote_abi_version() == 2
     assert b"gfx950" in lib.pvnet_vote_build_info()
 
 

@@ -51,6 +51,18 @@ for bi in range(B):
     inl_f = refkernels.voting_for_hypothesis(direct, coords, hyp, TH, contract="fast")
     tot["flips_fma"] += int((inl != inl_f).sum())
     tot["fast_diff"] += int((fast_counts[bi].T - counts).abs().sum())
+    # float64 truth of the same cosine test on the same float32 inputs (ransac_voting_kernel.cu:113-124 in exact arithmetic)
+    c64, u64, h64 = coords.double(), direct.double(), hyp.double()
+    cnt64 = torch.zeros_like(counts)
+    for k in range(9):
+        dxy = h64[:, k, None, :] - c64[None, :, :]                      # [hn,tn,2]
+        n1 = u64[:, k].norm(dim=1)[None, :]
+        n2 = dxy.norm(dim=2)
+        cosv = (dxy * u64[None, :, k, :]).sum(2) / (n1 * n2)
+        ok = (n1 >= 1e-6) & (n2 >= 1e-6) & (cosv > float(np.float32(TH)))
+        cnt64[:, k] = ok.sum(1).int()
+    tot["ref_vs_64"] = tot.get("ref_vs_64", 0) + int((counts - cnt64).abs().sum())
+    tot["fast_vs_64"] = tot.get("fast_vs_64", 0) + int((fast_counts[bi].T - cnt64).abs().sum())
     first = (counts == counts.max(0).values[None]).int().argmax(0)
     tot["win_lit"] += int((lit_win[bi, :, 0].long() == first).sum())
     tot["win_fast"] += int((fast_win[bi, :, 0].long() == first).sum())
@@ -61,6 +73,8 @@ print(f"inlier counts equal to the reference kernel (literal mode):  {tot['cnt_e
 print(f"winners equal to the reference kernel: literal {tot['win_lit']}/{tot['kp']}, fast {tot['win_fast']}/{tot['kp']}")
 print(f"fast mode: sum |count - reference count| = {tot['fast_diff']} over {tot['pairs']} pair tests "
       f"({tot['fast_diff'] / tot['pairs']:.2e})")
+print(f"against float64 arithmetic on the same inputs: sum |count diff| reference kernels {tot['ref_vs_64']} "
+      f"({tot['ref_vs_64'] / tot['pairs']:.2e}), fast mode {tot['fast_vs_64']} ({tot['fast_vs_64'] / tot['pairs']:.2e})")
 print(f"reference, fp-contract fast vs off: max relative hypothesis change {hyp_rel:.2e}; "
       f"inlier flags flipped {tot['flips_fma']} of {tot['pairs']} ({tot['flips_fma'] / tot['pairs']:.2e})")
 t = sorted(t_ref)[len(t_ref) // 2]

@@ -29,14 +29,18 @@ def run(n=10, **kw):
 
 
 configs = []
-for wgs, hpl, chunk in itertools.product([6, 8], [4, 8], [128, 256]):
-    configs.append(dict(PVNET_SCORE_WGS_PER_CU=wgs, PVNET_SCORE_HPL=hpl, PVNET_SCORE_CHUNK=chunk))
+DEFAULT_ENV = dict(PVNET_SCORE_MODE="", PVNET_SCORE_WGS_PER_CU="", PVNET_SCORE_HPL="", PVNET_SCORE_CHUNK="")
+if os.environ.get("TUNE_DEFAULTS", "1") == "1":
+    for wgs, hpl, chunk in itertools.product([4, 8], [4, 8], [128, 256]):
+        configs.append(dict(PVNET_SCORE_WGS_PER_CU=wgs, PVNET_SCORE_HPL=hpl, PVNET_SCORE_CHUNK=chunk))
 for extra in sys.argv[1:]:
     configs.append(dict(kv.split("=") for kv in extra.split(",")))
 ROUNDS = int(os.environ.get("TUNE_ROUNDS", 3))
 res = {}
 for rnd in range(ROUNDS):  # interleaved rounds: run-to-run drift is a few percent on this part
     for i, c in enumerate(configs):
+        for k in DEFAULT_ENV:  # every configuration starts from the library defaults
+            os.environ.pop(k, None)
         for k, x in c.items():
             os.environ[k] = str(x)
         res.setdefault(i, []).append(run())
