@@ -43,8 +43,9 @@ extern "C" {
 
 /* flags */
 #define PVNET_F_LITERAL   1u       /* score with the reference's float32 operation order (sqrt + divide, one
-                                      rounding per op): bit-exact with oracle32.  Default: the 6-op clamp-vote
-                                      form |d x u| < tan(acos(thresh)) * (d . u)  (pvnet_vote.hip: vote_expanded) */
+                                      rounding per op): bit-exact with oracle32 and with the reference's own
+                                      kernels.  Default: |d x u| < tan(acos(thresh)) * (d . u) evaluated as two
+                                      bf16x3 MFMAs + compare (pvnet_vote.hip: score_mfma_kernel), fp32-equivalent */
 #define PVNET_F_NO_REFINE 2u       /* skip ransac_voting_gpu.py:579-595, return the winning hypotheses */
 
 /* per-(image,key-point) status bits written to out_status */
@@ -61,7 +62,8 @@ typedef struct PvnetVoteLayout {
     int32_t words;          /* 64-pixel words per image in the foreground bit mask                          */
     int32_t chunk;          /* pixels per scoring work item                                                 */
     int32_t max_chunks;     /* ceil(cap / chunk)                                                            */
-    int32_t hpl;            /* hypotheses per lane in the scoring kernel                                    */
+    int32_t hpl;            /* hypotheses per lane of the VALU scoring kernel (literal mode); fast mode: a
+                               work item holds wg_g*64*hpl hypotheses = 4 waves x (wg_g*hpl/2) MFMA tiles of 32 */
     int32_t hgroups;        /* hypothesis groups per key-point = ceil(hn / (64*hpl)) rounded up to wg_g     */
     int32_t hn_pad;         /* hgroups * 64 * hpl                                                           */
     size_t off_ctrl;        /* int32 [b][8]: tn0, tn, status, item_base, nchunks, -, -, -  ; then [8] global */
@@ -127,7 +129,7 @@ int pvnet_vote_v3_logits(const float* seg_pred, const int64_t seg_strides[4], in
 #define PVNET_STAGE_SUBSAMPLE 1   /* Bernoulli subsample when tn0 > max_num                                  */
 #define PVNET_STAGE_COMPACT   2   /* order-preserving compaction + vector gather  (HBM read of fg vectors)   */
 #define PVNET_STAGE_HYP       3   /* hypothesis generation + per-image work-item plan                        */
-#define PVNET_STAGE_SCORE     4   /* inlier scoring (dominant, fp32 VALU)                                    */
+#define PVNET_STAGE_SCORE     4   /* inlier scoring (dominant; matrix pipe + VALU compare)                   */
 #define PVNET_STAGE_REFINE    5   /* arg-max + least-squares refinement                                      */
 #define PVNET_NUM_STAGES      6
 int pvnet_vote_v3_profiled(const void* mask, int mask_dtype, const int64_t mask_strides[3],

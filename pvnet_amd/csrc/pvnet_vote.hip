@@ -18,12 +18,16 @@
 //                     consecutive addresses) and writes ONE float4 record per (pixel, key-point):
 //                     (x, y, My, -Mx) with M = 2^90 * direction                                        [HBM read]
 //   K3 hypotheses     one thread per (image, kp, h): two pixel draws (counter RNG or caller idxs), 2x2 solve in
-//                     the reference's float32 order; one extra block per image plans the scoring work items
-//   K4 score          DOMINANT, fp32 VALU bound: 6 VALU ops per (hypothesis, pixel) test.  "Lane owns
-//                     hypotheses": every lane keeps HPL hypotheses and their float vote counters in VGPRs; a
-//                     workgroup stages the records of its pixel chunks in LDS once and its 4 waves read them
-//                     back as broadcast ds_read_b128/b64; the vote is the CLAMPed result of the last fma.
-//                     Work items are strided over a persistent grid; per-chunk counts go out as uint16 rows.
+//                     the reference's float32 order; also writes each hypothesis as a bf16x3 MFMA operand column;
+//                     one extra block per image plans the scoring work items
+//   K4 score          DOMINANT.  Fast mode (score_mfma_kernel): the vote is two 3-term fp32 dot products and a
+//                     compare; every operand is split into three bf16 parts, so each dot product is ONE
+//                     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (fp32-equivalent accuracy, measured), and
+//                     the lane that owns the hypothesis counts its 16 results with v_cmp + add-with-carry: 2 MFMAs
+//                     + 2 VALU ops per test.  Records are expanded and staged in LDS once per work item.
+//                     Literal mode (score_kernel<HPL,true>): "lane owns hypotheses" on the VALU in the
+//                     reference's float32 operation order, bit-exact with the reference's kernels.
+//                     Work items are strided over a persistent grid; counts go out as uint16 rows.
 //   K5 select+refine  sums the chunk counts, arg-max with first-index tie-break (wave shuffles), recomputes the
 //                     winner's inliers and solves the 2x2 normal equations, accumulated in float64 centred on
 //                     the winner (the reference's un-centred float32 sums are ~2e-3 px noisy).
@@ -550,7 +554,9 @@ __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K4: inlier scoring                                           (kernel.cu:88-126 + ransac_voting_gpu.py:557-561)
+// K4, VALU form: inlier scoring                               (kernel.cu:88-126 + ransac_voting_gpu.py:557-561)
+// Used by literal mode (the reference's float32 operation order); its fast-mode instantiation (6-op vote_expanded)
+// is what PVNET_SCORE_MODE=0 selects and what the matrix-pipe kernel below replaced (153-166 us -> 107-118 us).
 //
 // "Lane owns hypotheses": each lane keeps HPL hypotheses and their vote counters in VGPRs and walks the pixels of
 // a chunk; 6 VALU ops per (hypothesis, pixel) test in fast mode (vote_expanded), all on VGPR operands.
@@ -806,20 +812,16 @@ __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
         const uint32_t* pp = reinterpret_cast<const uint32_t*>(P.partial + bk * P.max_chunks * P.hn_pad) + h2;
         int lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
         int c = 0;
-        for (; c + 8 <= nch; c += 8) {
+        for (; c < nch; c += 8) {  // the last trip re-reads the final row for the slots past it and discards them
             uint32_t v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = pp[(size_t)(c + u) * row];
+            for (int u = 0; u < 8; ++u) v[u] = pp[(size_t)(c + u < nch ? c + u : nch - 1) * row];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                lo[u & 3] += (int)(v[u] & 0xFFFFu);
-                hi[u & 3] += (int)(v[u] >> 16);
+                const uint32_t x = c + u < nch ? v[u] : 0u;
+                lo[u & 3] += (int)(x & 0xFFFFu);
+                hi[u & 3] += (int)(x >> 16);
             }
-        }
-        for (; c < nch; ++c) {
-            const uint32_t v = pp[(size_t)c * row];
-            lo[0] += (int)(v & 0xFFFFu);
-            hi[0] += (int)(v >> 16);
         }
         const int s0 = (lo[0] + lo[1]) + (lo[2] + lo[3]), s1 = (hi[0] + hi[1]) + (hi[2] + hi[3]);
         const int h = 2 * h2;
@@ -1122,7 +1124,7 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
     {   // K4: persistent grid, work items strided over its waves
         const long long max_items =
             (long long)P.b * P.vn * (P.hgroups / P.wg_g) * ((P.max_chunks + P.wg_s - 1) / P.wg_s);
-        const int wgs_per_cu = env_int("PVNET_SCORE_WGS_PER_CU", (!literal && P.mode) ? 4 : 8);
+        const int wgs_per_cu = env_int("PVNET_SCORE_WGS_PER_CU", 8);
         long long wgs = wgs_per_cu > 0 ? (long long)num_cus() * wgs_per_cu : max_items;  // 0: one workgroup per item
         if (wgs > max_items) wgs = max_items;
         if (wgs < 1) wgs = 1;
