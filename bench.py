@@ -6,7 +6,10 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the whole voting path (mask + 9-key-point vector field -> 9 key-points) over one
-batch of 32 synthetic images per GPU, inputs resident in HBM.  With N > 1 every rank votes its own 32 images
+batch of 32 synthetic images per GPU, inputs resident in HBM.  Steps are independent batches, so they are issued
+round-robin on --streams HIP streams (default 4): the matrix-pipe scoring kernel holds 12 of a CU's 32 wave slots
+and the next batch's small latency-bound stages run beside it; `single_stream` in the output is the same K steps
+issued strictly one after the other.  With N > 1 every rank votes its own 32 images
 (weak scaling, no data-path collective) and the step ends with the path's one real exchange: an RCCL
 all-gather of the [32, 9, 2] key-points.  Rank 0 prints ONE JSON line.
 
@@ -54,11 +57,17 @@ N_SIMD = 256 * 4
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--prewarm-seconds", type=float, default=0.5,
+                    help="untimed steps issued before the W warmup steps so that short runs do not measure the GPU's "
+                         "clock ramp from idle (a step is ~0.15 ms: K=50 alone is an 8 ms burst)")
     ap.add_argument("--radius", type=int, default=40, help="disk radius of the synthetic object mask (tn ~ pi r^2)")
     ap.add_argument("--buffers", type=int, default=2, help="distinct input sets cycled (2 x 786 MB > 256 MiB L3)")
     ap.add_argument("--clean", action="store_true", help="noise-free field (default: noisy, net-like background)")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="HIP streams the steps are issued on round-robin (independent batches in flight; the scoring "
+                         "kernel keeps 12 of a CU's 32 wave slots, so the next batch's small stages run beside it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -169,20 +178,27 @@ def main():
     voting.load_library()
 
     sets = make_inputs(rank, a.buffers, a.radius, not a.clean, dev)
-    # double-buffered gather target: the 2.3 KB all-gather of step i (RCCL stream) overlaps the voting of step i+1
-    gathered = [torch.empty((world * BATCH, VN, 2), dtype=torch.float32, device=dev) for _ in range(2)] \
+    # S streams, S + 1 gather targets: the 2.3 KB all-gather of step i (RCCL stream) overlaps the voting of the
+    # following steps; a target is reused only after the gather that last wrote it has been waited for
+    nstreams = max(1, a.streams)
+    streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
+    gathered = [torch.empty((world * BATCH, VN, 2), dtype=torch.float32, device=dev) for _ in range(nstreams + 1)] \
         if world > 1 else None
     pending = []
 
-    def step(i, **kw):
+    def step(i, ns=nstreams, **kw):
         m, v, _, _ = sets[i % len(sets)]
-        out = voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=1234 + i, image_offset=rank * BATCH,
-                                            **kw)
-        if world > 1 and not kw:
-            # the path's single exchange: RCCL all-gather of the [32, 9, 2] key-points over xGMI
-            pending.append(dist.all_gather_into_tensor(gathered[i % 2], out, async_op=True))
-            if len(pending) > 1:
-                pending.pop(0).wait()  # step i-1's gather must be done before its buffer is reused at step i+1
+        if kw:  # profiled / debug calls: current stream, synchronising
+            return voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=1234 + i,
+                                                 image_offset=rank * BATCH, **kw)
+        with torch.cuda.stream(streams[i % ns]):
+            out = voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=1234 + i,
+                                                image_offset=rank * BATCH)
+            if world > 1:
+                # the path's single exchange: RCCL all-gather of the [32, 9, 2] key-points over xGMI
+                pending.append(dist.all_gather_into_tensor(gathered[i % (nstreams + 1)], out, async_op=True))
+                if len(pending) > ns:
+                    pending.pop(0).wait()
         return out
 
     def fence():
@@ -193,30 +209,46 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(a.warmup):
-        step(i)
+    def timed(ns):
+        for i in range(a.warmup):
+            step(i, ns)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(i, ns)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    t_pre = time.perf_counter()                      # device pre-warm (untimed, reported in config.prewarm_s)
+    i_pre = 0
+    while time.perf_counter() - t_pre < a.prewarm_seconds:
+        for _ in range(20):  # voting only: a time-bounded loop must not issue collectives (ranks would disagree on the count)
+            m, v, _, _ = sets[i_pre % len(sets)]
+            with torch.cuda.stream(streams[i_pre % nstreams]):
+                voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=i_pre, image_offset=rank * BATCH)
+            i_pre += 1
+        torch.cuda.synchronize(dev)
     fence()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed(nstreams)                             # the headline: K steps, independent batches on S streams
+    dt1 = timed(1) if nstreams > 1 else dt           # the same K steps strictly one after the other (latency view)
 
     # ---- roofline of the dominant kernel: live hipEvent stage timing over the same K steps ------------------
     stage_sum = {}
     tn_sum = 0
-    for i in range(a.steps):
+    nprof = min(a.steps, 200)  # synchronising, profiled calls: 200 are plenty for an average
+    for i in range(nprof):
         _, dbg, times = step(i, return_debug=True, stage_times=True)
         if i < len(sets):
             tn_sum += int(dbg["tn"].sum().item())
         for k, v in times.items():
             stage_sum[k] = stage_sum.get(k, 0.0) + v
-    stage_ms = {k: v / a.steps for k, v in stage_sum.items()}
-    tn_per_batch = tn_sum / min(a.steps, len(sets))
+    stage_ms = {k: v / nprof for k, v in stage_sum.items()}
+    tn_per_batch = tn_sum / min(nprof, len(sets))
     pairs = HN * VN * tn_per_batch  # pair tests per launch of the scoring kernel
     score_s = stage_ms["score"] * 1e-3
     path_s = sum(stage_ms.values()) * 1e-3
@@ -227,13 +259,17 @@ def main():
             "metric": "RANSAC votings/s (480x640, 9 kpts, batch 32) + HBM GB/s vs roofline",
             "value": votings_per_s, "unit": "votings/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "single_stream": {"value": world * BATCH * a.steps / dt1, "ms_per_step": dt1 / a.steps * 1e3,
+                              "note": "the same K steps issued on one stream: per-batch latency of the whole path"},
             "dtype": "bf16x3 products, f32 accumulate (f32-equivalent; refinement f64)", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[2]: batch=32 synthetic 480x640 fields per GPU, 9 keypoints, "
                                    "1024 hypotheses, inlier_thresh 0.99, int64 mask, planar strided field",
                        "batch_per_gpu": BATCH, "global_batch": world * BATCH, "h": H, "w": W, "vn": VN, "hn": HN,
                        "mask_radius": a.radius, "mean_foreground_px": tn_per_batch / BATCH,
                        "field": "clean" if a.clean else "noisy (0.05 rad + 10% outliers), N(0,1) background",
-                       "input_sets_cycled": len(sets), "parallelism": f"images sharded over {world} GPU(s)"},
+                       "input_sets_cycled": len(sets), "streams": nstreams, "prewarm_s": a.prewarm_seconds,
+                       "parallelism": f"images sharded over {world} GPU(s); steps issued round-robin on {nstreams} "
+                                      f"HIP stream(s) per GPU"},
             "roofline": {"kernel": "score_mfma_kernel", "bound": "mfma",
                          "achieved": MFMA_FLOP_PER_PAIR * pairs / score_s / 1e12, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": MFMA_FLOP_PER_PAIR * pairs / score_s / 1e12 / PEAK_BF16_TFLOPS,

@@ -5,10 +5,10 @@ cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-python bench.py --steps 50 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; tail -c 3000 $OUT/bench.json
-( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/trace_bench.json 2> $OUT/trace.err )
-( cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err )
-( cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/pmc_write.json 2> $OUT/pmc_write.err )
-( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY -d $OUT/pmc_sq -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err )
+python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 3000 $OUT/bench.json
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --streams 1 --prewarm-seconds 0.2 --no-cpu-baseline > $OUT/trace_bench.json 2> $OUT/trace.err )
+( cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --streams 1 --prewarm-seconds 0 --no-cpu-baseline > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err )
+( cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --streams 1 --prewarm-seconds 0 --no-cpu-baseline > $OUT/pmc_write.json 2> $OUT/pmc_write.err )
+( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY -d $OUT/pmc_sq -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --streams 1 --prewarm-seconds 0 --no-cpu-baseline > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err )
 find $OUT -name "*.csv" | head -30
 ls -la $OUT/trace/* | head
