@@ -13,7 +13,7 @@ from pvnet_amd import synth, voting  # noqa: E402
 dev = torch.device("cuda:0")
 
 
-def run(name, b, radius, hn, thresh, max_num=30000, mask_dtype=torch.int64, steps=30, **kw):
+def run(name, b, radius, hn, thresh, max_num=30000, mask_dtype=torch.int64, steps=100, **kw):
     mask, planar, _ = synth.make_batch(b, radius=radius, noise=True, background="normal")
     m = torch.from_numpy(mask).to(dev).to(mask_dtype)
     v = synth.planar_to_vertex_view(torch.from_numpy(planar).to(dev))
@@ -41,3 +41,5 @@ run("eval call site: b=1 hn=128 max_num=100", 1, 40, 128, 0.99, max_num=100)
 run("batch 8", 8, 40, 1024, 0.99)
 run("batch 128", 128, 40, 1024, 0.99, steps=10)
 run("literal mode (reference fp32 order)", 32, 40, 1024, 0.99, literal=True, steps=5)
+run("hn=4096 (distribution estimate), b=8", 8, 40, 4096, 0.99, steps=10)
+run("hn=256, b=32", 32, 40, 256, 0.99)
