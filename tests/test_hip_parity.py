@@ -502,3 +502,25 @@ def test_randomised_shapes_literal_vs_c_oracle(case):
     assert np.abs(out.cpu().numpy() - ref)[good].max() < 2e-3 * max(1.0, np.abs(ref[good]).max() / 100)
     fast = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, max_num=max_num, seed=seed)
     assert torch.isfinite(fast).all()
+
+
+def test_concurrent_streams_reproduce_serial_results():
+    """Independent batches in flight on several HIP streams (what bench.py does): every call owns its workspace, so the
+    results must be bit-identical to the same calls issued one after the other."""
+    sets = []
+    for i in range(2):
+        mask, planar, _, _ = small_batch(b=6, first=900 + 10 * i, h=240, w=320, radius=30)
+        sets.append(to_dev(mask, planar))
+    serial = [voting.ransac_voting_layer_v3(*sets[i % 2], 512, inlier_thresh=0.99, seed=50 + i).clone()
+              for i in range(12)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(dev()) for _ in range(4)]
+    outs = []
+    for rep in range(3):  # three rounds: workspaces get recycled by the caching allocator between streams
+        outs = []
+        for i in range(12):
+            with torch.cuda.stream(streams[i % 4]):
+                outs.append(voting.ransac_voting_layer_v3(*sets[i % 2], 512, inlier_thresh=0.99, seed=50 + i))
+        torch.cuda.synchronize()
+        for a, b in zip(serial, outs):
+            assert torch.equal(a, b)
