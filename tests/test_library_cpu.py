@@ -32,7 +32,7 @@ def test_exports_every_declared_symbol(lib):
 
 def test_library_contains_gfx950_code_object():
     blob = open(voting.LIB_PATH, "rb").read()
-    assert b"gfx950" in blob and b"score_kernel" in blob
+    assert b"gfx950" in blob and b"score_kernel" in blob and b"score_mfma_kernel" in blob
 
 
 def test_layout_baseline_config(lib):

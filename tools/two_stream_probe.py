@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pvnet_amd import synth, voting  # noqa: E402
 
 dev = torch.device("cuda:0")
-B, K = 32, 100
+B, K = 32, int(os.environ.get('PROBE_K', 100))
 sets = []
 for i in range(2):
     mask, planar, _ = synth.make_batch(B, first_index=1000 * i, radius=40, noise=True, background="normal")
@@ -33,6 +33,6 @@ def run(nstreams):
     return (time.perf_counter() - t0) / K, t_issue / K
 
 
-for n in (1, 2, 4, 1, 4, 8, 1, 4):
+for n in ([int(x) for x in os.environ['PROBE_STREAMS'].split(',')] if 'PROBE_STREAMS' in os.environ else (1, 2, 4, 1, 4, 8, 1, 4)):
     dt, ti = run(n)
     print(f"{n} stream(s): {dt * 1e3:.4f} ms per batch of {B} -> {B / dt:,.0f} votings/s   (host issue {ti * 1e3:.4f} ms per call)", flush=True)
