@@ -23,8 +23,8 @@
 //   K4 score          DOMINANT.  Fast mode (score_mfma_kernel): the vote is two 3-term fp32 dot products and a
 //                     compare; every operand is split into three bf16 parts, so each dot product is ONE
 //                     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (fp32-equivalent accuracy, measured), and
-//                     the lane that owns the hypothesis counts its 16 results with v_cmp + add-with-carry: 2 MFMAs
-//                     + 2 VALU ops per test.  Records are expanded and staged in LDS once per work item.
+//                     the lane that owns the hypothesis counts its 16 results with cnt += clamp(dt - |cr|)
+//                     (the 2^90 record scaling makes the clamp an exact 0/1): 2 MFMAs + 2 VALU ops per test.  Records are expanded and staged in LDS once per work item.
 //                     Literal mode (score_kernel<HPL,true>): "lane owns hypotheses" on the VALU in the
 //                     reference's float32 operation order, bit-exact with the reference's kernels.
 //                     Work items are strided over a persistent grid; counts go out as uint16 rows.
@@ -659,37 +659,38 @@ __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
 // 4 * MH * 32 hypotheses).  The workgroup turns the group's records into bf16x3 A rows in LDS (32-pixel tiles,
 // A_cr | A_dt); each of its 4 waves keeps the B columns of MH * 32 hypotheses in registers (written by K3) and, per
 // tile, issues 2 MFMAs per 32 hypotheses: cr and dt of 32 x 32 (pixel, hypothesis) pairs land in the lane that
-// owns the hypothesis (column = lane & 31, 16 rows per lane), so the vote is v_cmp(dt > |cr|) + add-with-carry:
+// owns the hypothesis (column = lane & 31, 16 rows per lane), so the vote is cnt += clamp(dt - |cr|) (vote8):
 // 2 VALU operations per test instead of 6, the other four run on the matrix pipe at bf16 rate.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int TILE_U4 = 128;  // uint4 per 32-pixel tile: A_cr rows (32 x 2) then A_dt rows (32 x 2)
 
-// Eight votes of the lane's hypothesis: cnt += (dt > |cr|) for eight (dt, cr) pairs, 2 VALU operations per test.
-// Hand-placed so that every SGPR mask is consumed >= 3 instructions after the compare that wrote it (the
-// "VALU writes SGPR -> VALU reads it" hazard of gfx940+ costs hipcc an s_nop per pair otherwise).
-__device__ __forceinline__ void vote8(int& cnt, float d0, float c0, float d1, float c1, float d2, float c2, float d3,
+// Eight votes of the lane's hypothesis: cnt += clamp(dt - |cr|) for eight (dt, cr) pairs, 2 plain VALU operations
+// per test.  The records carry M = 2^90 * direction, so any non-zero margin is >= 1 in magnitude and the clamp
+// output modifier turns it into exactly 1.0f or 0.0f (NaN -> 0): no compare, no SGPR mask, no carry chain -- measured
+// 5-7 % faster beside MFMAs than v_cmp + v_cndmask + v_addc (tools/ubench_mfma.hip).  Float counters are exact
+// below 2^24 votes.  Hand-placed: every difference is consumed >= 3 instructions after it was produced.
+__device__ __forceinline__ void vote8(float& cnt, float d0, float c0, float d1, float c1, float d2, float c2, float d3,
                                       float c3, float d4, float c4, float d5, float c5, float d6, float c6, float d7,
                                       float c7) {
-    unsigned long long m0, m1, m2, m3;
-    int x, y;
+    float t0, t1, t2, t3;
     asm volatile(
-        "v_cmp_gt_f32_e64 %1, %7, |%8|\n"
-        "v_cmp_gt_f32_e64 %2, %9, |%10|\n"
-        "v_cmp_gt_f32_e64 %3, %11, |%12|\n"
-        "v_cmp_gt_f32_e64 %4, %13, |%14|\n"
-        "v_cndmask_b32_e64 %5, 0, 1, %1\n"
-        "v_cmp_gt_f32_e64 %1, %15, |%16|\n"
-        "v_addc_co_u32_e64 %0, %2, %0, %5, %2\n"
-        "v_cndmask_b32_e64 %6, 0, 1, %3\n"
-        "v_cmp_gt_f32_e64 %2, %17, |%18|\n"
-        "v_addc_co_u32_e64 %0, %4, %0, %6, %4\n"
-        "v_cmp_gt_f32_e64 %3, %19, |%20|\n"
-        "v_cmp_gt_f32_e64 %4, %21, |%22|\n"
-        "v_cndmask_b32_e64 %5, 0, 1, %1\n"
-        "v_cndmask_b32_e64 %6, 0, 1, %3\n"
-        "v_addc_co_u32_e64 %0, %2, %0, %5, %2\n"
-        "v_addc_co_u32_e64 %0, %4, %0, %6, %4\n"
-        : "+v"(cnt), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&v"(x), "=&v"(y)
+        "v_sub_f32_e64 %1, %5, |%6| clamp\n"
+        "v_sub_f32_e64 %2, %7, |%8| clamp\n"
+        "v_sub_f32_e64 %3, %9, |%10| clamp\n"
+        "v_sub_f32_e64 %4, %11, |%12| clamp\n"
+        "v_add_f32_e32 %0, %0, %1\n"
+        "v_sub_f32_e64 %1, %13, |%14| clamp\n"
+        "v_add_f32_e32 %0, %0, %2\n"
+        "v_sub_f32_e64 %2, %15, |%16| clamp\n"
+        "v_add_f32_e32 %0, %0, %3\n"
+        "v_sub_f32_e64 %3, %17, |%18| clamp\n"
+        "v_add_f32_e32 %0, %0, %4\n"
+        "v_sub_f32_e64 %4, %19, |%20| clamp\n"
+        "v_add_f32_e32 %0, %0, %1\n"
+        "v_add_f32_e32 %0, %0, %2\n"
+        "v_add_f32_e32 %0, %0, %3\n"
+        "v_add_f32_e32 %0, %0, %4\n"
+        : "+v"(cnt), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
         : "v"(d0), "v"(c0), "v"(d1), "v"(c1), "v"(d2), "v"(c2), "v"(d3), "v"(c3), "v"(d4), "v"(c4), "v"(d5), "v"(c5),
           "v"(d6), "v"(c6), "v"(d7), "v"(c7));
 }
@@ -735,9 +736,9 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
         }
         __syncthreads();
 
-        int cnt[MH];
+        float cnt[MH];
 #pragma unroll
-        for (int t = 0; t < MH; ++t) cnt[t] = 0;
+        for (int t = 0; t < MH; ++t) cnt[t] = 0.f;
         // Flat software pipeline over (pixel tile, hypothesis tile) steps: the two MFMAs of step i+1 are issued
         // around the votes of step i (half of them behind each), on ping-pong accumulators.
         bf16x8 Acr = __builtin_bit_cast(bf16x8, lbase[0]), Adt = __builtin_bit_cast(bf16x8, lbase[64]);
@@ -769,7 +770,8 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
         uint16_t* po = P.partial + (bk * P.max_chunks + cg) * P.hn_pad + h0;
 #pragma unroll
         for (int t = 0; t < MH; ++t) {
-            const int c = cnt[t] + __shfl_xor(cnt[t], 32, 64);  // the half-waves hold different rows of the column
+            const int ci = (int)cnt[t];
+            const int c = ci + __shfl_xor(ci, 32, 64);  // the half-waves hold different rows of the column
             if (half == 0) po[t * 32 + col] = (uint16_t)c;
         }
     }

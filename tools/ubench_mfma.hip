@@ -130,6 +130,32 @@ __device__ __forceinline__ void vote8(int& cnt, float d0, float c0, float d1, fl
         : "v"(d0), "v"(c0), "v"(d1), "v"(c1), "v"(d2), "v"(c2), "v"(d3), "v"(c3), "v"(d4), "v"(c4), "v"(d5), "v"(c5),
           "v"(d6), "v"(c6), "v"(d7), "v"(c7));
 }
+// plain-VALU epilogue: s = clamp(d - |c|) (0/1 when the operands carry the 2^90 record scaling), cnt += s
+__device__ __forceinline__ void vote8f(float& cnt, float d0, float c0, float d1, float c1, float d2, float c2, float d3,
+                                       float c3, float d4, float c4, float d5, float c5, float d6, float c6, float d7,
+                                       float c7) {
+    float t0, t1, t2, t3;
+    asm volatile(
+        "v_sub_f32_e64 %1, %5, |%6| clamp\n"
+        "v_sub_f32_e64 %2, %7, |%8| clamp\n"
+        "v_sub_f32_e64 %3, %9, |%10| clamp\n"
+        "v_sub_f32_e64 %4, %11, |%12| clamp\n"
+        "v_add_f32_e32 %0, %0, %1\n"
+        "v_sub_f32_e64 %1, %13, |%14| clamp\n"
+        "v_add_f32_e32 %0, %0, %2\n"
+        "v_sub_f32_e64 %2, %15, |%16| clamp\n"
+        "v_add_f32_e32 %0, %0, %3\n"
+        "v_sub_f32_e64 %3, %17, |%18| clamp\n"
+        "v_add_f32_e32 %0, %0, %4\n"
+        "v_sub_f32_e64 %4, %19, |%20| clamp\n"
+        "v_add_f32_e32 %0, %0, %1\n"
+        "v_add_f32_e32 %0, %0, %2\n"
+        "v_add_f32_e32 %0, %0, %3\n"
+        "v_add_f32_e32 %0, %0, %4\n"
+        : "+v"(cnt), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(d0), "v"(c0), "v"(d1), "v"(c1), "v"(d2), "v"(c2), "v"(d3), "v"(c3), "v"(d4), "v"(c4), "v"(d5), "v"(c5),
+          "v"(d6), "v"(c6), "v"(d7), "v"(c7));
+}
 __device__ __forceinline__ void vote16(int& cnt, const f32x16& d, const f32x16& c) {
     vote8(cnt, d[0], c[0], d[1], c[1], d[2], c[2], d[3], c[3], d[4], c[4], d[5], c[5], d[6], c[6], d[7], c[7]);
     vote8(cnt, d[8], c[8], d[9], c[9], d[10], c[10], d[11], c[11], d[12], c[12], d[13], c[13], d[14], c[14], d[15], c[15]);
@@ -143,11 +169,13 @@ __global__ __launch_bounds__(256) void k_mfma_vote2(const float* __restrict__ hy
     stage_pixels(pixc + (size_t)blockIdx.y * ntiles * 32 * 6, ntiles * 32, lds);
     bf16x8 B[MH];
     int cnt[MH];
+    float fcnt[MH];
 #pragma unroll
     for (int t = 0; t < MH; ++t) {
         const int j = (wave * MH + t) * 32 + (lane & 31);
         B[t] = make_b(hyp[j * 2], hyp[j * 2 + 1], half);
         cnt[t] = 0;
+        fcnt[t] = 0.f;
     }
     __syncthreads();
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -165,7 +193,16 @@ __global__ __launch_bounds__(256) void k_mfma_vote2(const float* __restrict__ hy
 #pragma unroll
                 for (int t = 0; t < MH; ++t) {
                     f32x16 cr2, d2;
-                    if (PIPE == 2) {  // half of the votes in the shadow of each MFMA
+                    if (PIPE == 3) {  // as PIPE == 2 with the plain-VALU float epilogue
+                        cr2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Acr : Ncr, B[(t + 1) % MH], zero, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        vote8f(fcnt[t], d[0], cr[0], d[1], cr[1], d[2], cr[2], d[3], cr[3], d[4], cr[4], d[5], cr[5], d[6], cr[6], d[7], cr[7]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Ad : Nd, B[(t + 1) % MH], zero, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        vote8f(fcnt[t], d[8], cr[8], d[9], cr[9], d[10], cr[10], d[11], cr[11], d[12], cr[12], d[13], cr[13], d[14], cr[14], d[15], cr[15]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (PIPE == 2) {  // half of the votes in the shadow of each MFMA
                         cr2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Acr : Ncr, B[(t + 1) % MH], zero, 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                         vote8(cnt[t], d[0], cr[0], d[1], cr[1], d[2], cr[2], d[3], cr[3], d[4], cr[4], d[5], cr[5], d[6], cr[6], d[7], cr[7]);
@@ -210,7 +247,8 @@ __global__ __launch_bounds__(256) void k_mfma_vote2(const float* __restrict__ hy
     }
 #pragma unroll
     for (int t = 0; t < MH; ++t) {
-        const int c = cnt[t] + __shfl_xor(cnt[t], 32, 64);
+        const int ci = PIPE == 3 ? (int)fcnt[t] : cnt[t];
+        const int c = ci + __shfl_xor(ci, 32, 64);
         if (half == 0) counts[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 * MH * 32 + (wave * MH + t) * 32 + lane] = c;
     }
 }
@@ -284,11 +322,12 @@ int main() {
         ms /= 5;
         const double tests = (double)g.x * nh * npix * reps;
         printf("waves/SIMD %d  bf16x3 mfma vote (MH=%d): %8.3f ms  %7.2f Tpairs/s\n", wpc, MH, ms, tests / ms / 1e9);
-        for (int variant = 0; variant < 3; ++variant) {
+        for (int variant = 0; variant < 4; ++variant) {
             auto launch = [&] {
                 if (variant == 0) hipLaunchKernelGGL((k_mfma_vote2<MH, 0>), g, b, ntiles * TILE_BYTES, 0, dh, dp, dc, ntiles, reps);
                 else if (variant == 1) hipLaunchKernelGGL((k_mfma_vote2<MH, 1>), g, b, ntiles * TILE_BYTES, 0, dh, dp, dc, ntiles, reps);
-                else hipLaunchKernelGGL((k_mfma_vote2<MH, 2>), g, b, ntiles * TILE_BYTES, 0, dh, dp, dc, ntiles, reps);
+                else if (variant == 2) hipLaunchKernelGGL((k_mfma_vote2<MH, 2>), g, b, ntiles * TILE_BYTES, 0, dh, dp, dc, ntiles, reps);
+                else hipLaunchKernelGGL((k_mfma_vote2<MH, 3>), g, b, ntiles * TILE_BYTES, 0, dh, dp, dc, ntiles, reps);
             };
             launch();
             hipDeviceSynchronize();
@@ -298,7 +337,7 @@ int main() {
             hipEventSynchronize(e1);
             hipEventElapsedTime(&ms, e0, e1);
             ms /= 5;
-            printf("waves/SIMD %d    asm epilogue%s: %8.3f ms  %7.2f Tpairs/s\n", wpc, variant == 2 ? " + interleaved" : variant ? " + pipelined  " : "              ", ms, tests / ms / 1e9);
+            printf("waves/SIMD %d    asm epilogue%s: %8.3f ms  %7.2f Tpairs/s\n", wpc, variant == 3 ? " float clamp, interleaved" : variant == 2 ? " + interleaved" : variant ? " + pipelined  " : "              ", ms, tests / ms / 1e9);
         }
     }
     return 0;
