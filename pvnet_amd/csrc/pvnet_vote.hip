@@ -664,12 +664,17 @@ __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
 // ------------------------------------------------------------------------------------------------------------
 constexpr int TILE_U4 = 128;  // uint4 per 32-pixel tile: A_cr rows (32 x 2) then A_dt rows (32 x 2)
 
-// Eight votes of the lane's hypothesis: cnt += clamp(dt - |cr|) for eight (dt, cr) pairs, 2 plain VALU operations
-// per test.  The records carry M = 2^90 * direction, so any non-zero margin is >= 1 in magnitude and the clamp
-// output modifier turns it into exactly 1.0f or 0.0f (NaN -> 0): no compare, no SGPR mask, no carry chain -- measured
-// 5-7 % faster beside MFMAs than v_cmp + v_cndmask + v_addc (tools/ubench_mfma.hip).  Float counters are exact
-// below 2^24 votes.  Hand-placed: every difference is consumed >= 3 instructions after it was produced.
-__device__ __forceinline__ void vote8(float& cnt, float d0, float c0, float d1, float c1, float d2, float c2, float d3,
+// Eight votes of the lane's hypothesis, 1.5 plain VALU operations per test.  The records carry M = 2^90 * direction,
+// so any non-zero margin is >= 1 in magnitude and the clamp output modifier turns t = clamp(dt - |cr|) into exactly
+// 1.0f or 0.0f (NaN -> 0), i.e. the bit pattern 0x3F800000 or 0: no compare, no SGPR mask, no carry chain.  v_add3_u32
+// then sums TWO of them per instruction into a 32-bit integer that is allowed to wrap:
+//     acc = n * 0x3F800000 mod 2^32 = ((127 n) mod 512) << 23,
+// and 127 is invertible mod 512 (127 * 383 = 95 * 512 + 1), so n = ((acc >> 23) * 383) & 511 for any n < 512
+// (votes_of()).  A lane accumulates 16 tests per pixel tile and at most 16 tiles per work item (256 < 512).
+// Measured beside the MFMAs (tools/ubench_mfma.hip): 18.3 T tests/s against 16.5 T for v_sub clamp + v_add_f32 and
+// 15.7 T for v_cmp + v_cndmask + v_addc.  Hand-placed: every difference is consumed >= 3 instructions after it was
+// produced.
+__device__ __forceinline__ void vote8(unsigned& acc, float d0, float c0, float d1, float c1, float d2, float c2, float d3,
                                       float c3, float d4, float c4, float d5, float c5, float d6, float c6, float d7,
                                       float c7) {
     float t0, t1, t2, t3;
@@ -678,22 +683,20 @@ __device__ __forceinline__ void vote8(float& cnt, float d0, float c0, float d1, 
         "v_sub_f32_e64 %2, %7, |%8| clamp\n"
         "v_sub_f32_e64 %3, %9, |%10| clamp\n"
         "v_sub_f32_e64 %4, %11, |%12| clamp\n"
-        "v_add_f32_e32 %0, %0, %1\n"
+        "v_add3_u32 %0, %1, %2, %0\n"
         "v_sub_f32_e64 %1, %13, |%14| clamp\n"
-        "v_add_f32_e32 %0, %0, %2\n"
         "v_sub_f32_e64 %2, %15, |%16| clamp\n"
-        "v_add_f32_e32 %0, %0, %3\n"
+        "v_add3_u32 %0, %3, %4, %0\n"
         "v_sub_f32_e64 %3, %17, |%18| clamp\n"
-        "v_add_f32_e32 %0, %0, %4\n"
         "v_sub_f32_e64 %4, %19, |%20| clamp\n"
-        "v_add_f32_e32 %0, %0, %1\n"
-        "v_add_f32_e32 %0, %0, %2\n"
-        "v_add_f32_e32 %0, %0, %3\n"
-        "v_add_f32_e32 %0, %0, %4\n"
-        : "+v"(cnt), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        "v_add3_u32 %0, %1, %2, %0\n"
+        "v_add3_u32 %0, %3, %4, %0\n"
+        : "+v"(acc), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
         : "v"(d0), "v"(c0), "v"(d1), "v"(c1), "v"(d2), "v"(c2), "v"(d3), "v"(c3), "v"(d4), "v"(c4), "v"(d5), "v"(c5),
           "v"(d6), "v"(c6), "v"(d7), "v"(c7));
 }
+constexpr int VOTE_WRAP = 512;  // vote8 accumulators hold their count mod 512
+__device__ __forceinline__ int votes_of(unsigned acc) { return (int)(((acc >> 23) * 383u) & 511u); }
 
 template <int MH>
 __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
@@ -736,9 +739,9 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
         }
         __syncthreads();
 
-        float cnt[MH];
+        unsigned cnt[MH];  // wrapped vote accumulators (vote8): 16 * ntiles <= 256 votes each
 #pragma unroll
-        for (int t = 0; t < MH; ++t) cnt[t] = 0.f;
+        for (int t = 0; t < MH; ++t) cnt[t] = 0u;
         // Flat software pipeline over (pixel tile, hypothesis tile) steps: the two MFMAs of step i+1 are issued
         // around the votes of step i (half of them behind each), on ping-pong accumulators.
         bf16x8 Acr = __builtin_bit_cast(bf16x8, lbase[0]), Adt = __builtin_bit_cast(bf16x8, lbase[64]);
@@ -770,7 +773,7 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
         uint16_t* po = P.partial + (bk * P.max_chunks + cg) * P.hn_pad + h0;
 #pragma unroll
         for (int t = 0; t < MH; ++t) {
-            const int ci = (int)cnt[t];
+            const int ci = votes_of(cnt[t]);
             const int c = ci + __shfl_xor(ci, 32, 64);  // the half-waves hold different rows of the column
             if (half == 0) po[t * 32 + col] = (uint16_t)c;
         }
@@ -1236,6 +1239,8 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     chunk = env_int("PVNET_SCORE_CHUNK", chunk);
     if (chunk < PAD || chunk % PAD != 0 || chunk > 1024) return PVNET_E_UNSUPPORTED;  // LDS: 4 * 1024 * 32 B
     if (mode && chunk % 32 != 0) return PVNET_E_UNSUPPORTED;  // whole 32-pixel MFMA tiles
+    // a matrix-pipe work item is (4 / wg_g) * chunk pixels; its wrapped vote accumulators hold 16 votes per 32-pixel tile
+    if (mode && (4 / wg_g) * chunk / 2 >= VOTE_WRAP) return PVNET_E_UNSUPPORTED;
     L->b = b; L->h = h; L->w = w; L->vn = vn; L->hn = hn;
     L->cap = (int)cap;
     L->words = (int)((npix + 63) / 64);

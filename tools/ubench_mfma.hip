@@ -156,6 +156,30 @@ __device__ __forceinline__ void vote8f(float& cnt, float d0, float c0, float d1,
         : "v"(d0), "v"(c0), "v"(d1), "v"(c1), "v"(d2), "v"(c2), "v"(d3), "v"(c3), "v"(d4), "v"(c4), "v"(d5), "v"(c5),
           "v"(d6), "v"(c6), "v"(d7), "v"(c7));
 }
+// 1.5-op epilogue: t = clamp(d - |c|) is the bit pattern 0x3F800000 or 0; v_add3_u32 sums two of them per
+// instruction in a 32-bit integer that wraps: acc = n * 0x3F800000 mod 2^32 = ((127 n) mod 512) << 23, and 127 is
+// invertible mod 512 (127 * 383 = 95 * 512 + 1), so n = (((acc >> 23) * 383) & 511) as long as n < 512
+__device__ __forceinline__ void vote8i(unsigned& acc, float d0, float c0, float d1, float c1, float d2, float c2, float d3,
+                                       float c3, float d4, float c4, float d5, float c5, float d6, float c6, float d7,
+                                       float c7) {
+    float t0, t1, t2, t3;
+    asm volatile(
+        "v_sub_f32_e64 %1, %5, |%6| clamp\n"
+        "v_sub_f32_e64 %2, %7, |%8| clamp\n"
+        "v_sub_f32_e64 %3, %9, |%10| clamp\n"
+        "v_sub_f32_e64 %4, %11, |%12| clamp\n"
+        "v_add3_u32 %0, %1, %2, %0\n"
+        "v_sub_f32_e64 %1, %13, |%14| clamp\n"
+        "v_sub_f32_e64 %2, %15, |%16| clamp\n"
+        "v_add3_u32 %0, %3, %4, %0\n"
+        "v_sub_f32_e64 %3, %17, |%18| clamp\n"
+        "v_sub_f32_e64 %4, %19, |%20| clamp\n"
+        "v_add3_u32 %0, %1, %2, %0\n"
+        "v_add3_u32 %0, %3, %4, %0\n"
+        : "+v"(acc), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(d0), "v"(c0), "v"(d1), "v"(c1), "v"(d2), "v"(c2), "v"(d3), "v"(c3), "v"(d4), "v"(c4), "v"(d5), "v"(c5),
+          "v"(d6), "v"(c6), "v"(d7), "v"(c7));
+}
 __device__ __forceinline__ void vote16(int& cnt, const f32x16& d, const f32x16& c) {
     vote8(cnt, d[0], c[0], d[1], c[1], d[2], c[2], d[3], c[3], d[4], c[4], d[5], c[5], d[6], c[6], d[7], c[7]);
     vote8(cnt, d[8], c[8], d[9], c[9], d[10], c[10], d[11], c[11], d[12], c[12], d[13], c[13], d[14], c[14], d[15], c[15]);
@@ -170,12 +194,14 @@ __global__ __launch_bounds__(256) void k_mfma_vote2(const float* __restrict__ hy
     bf16x8 B[MH];
     int cnt[MH];
     float fcnt[MH];
+    unsigned ucnt[MH];
 #pragma unroll
     for (int t = 0; t < MH; ++t) {
         const int j = (wave * MH + t) * 32 + (lane & 31);
         B[t] = make_b(hyp[j * 2], hyp[j * 2 + 1], half);
         cnt[t] = 0;
         fcnt[t] = 0.f;
+        ucnt[t] = 0u;
     }
     __syncthreads();
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -193,7 +219,16 @@ __global__ __launch_bounds__(256) void k_mfma_vote2(const float* __restrict__ hy
 #pragma unroll
                 for (int t = 0; t < MH; ++t) {
                     f32x16 cr2, d2;
-                    if (PIPE == 3) {  // as PIPE == 2 with the plain-VALU float epilogue
+                    if (PIPE == 4) {  // as PIPE == 2 with the 1.5-op wrapped-integer epilogue
+                        cr2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Acr : Ncr, B[(t + 1) % MH], zero, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        vote8i(ucnt[t], d[0], cr[0], d[1], cr[1], d[2], cr[2], d[3], cr[3], d[4], cr[4], d[5], cr[5], d[6], cr[6], d[7], cr[7]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Ad : Nd, B[(t + 1) % MH], zero, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        vote8i(ucnt[t], d[8], cr[8], d[9], cr[9], d[10], cr[10], d[11], cr[11], d[12], cr[12], d[13], cr[13], d[14], cr[14], d[15], cr[15]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (PIPE == 3) {  // as PIPE == 2 with the plain-VALU float epilogue
                         cr2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Acr : Ncr, B[(t + 1) % MH], zero, 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                         vote8f(fcnt[t], d[0], cr[0], d[1], cr[1], d[2], cr[2], d[3], cr[3], d[4], cr[4], d[5], cr[5], d[6], cr[6], d[7], cr[7]);
@@ -247,9 +282,69 @@ __global__ __launch_bounds__(256) void k_mfma_vote2(const float* __restrict__ hy
     }
 #pragma unroll
     for (int t = 0; t < MH; ++t) {
-        const int ci = PIPE == 3 ? (int)fcnt[t] : cnt[t];
+        const int ci = PIPE == 4 ? (int)(((ucnt[t] >> 23) * 383u) & 511u) : PIPE == 3 ? (int)fcnt[t] : cnt[t];
         const int c = ci + __shfl_xor(ci, 32, 64);
         if (half == 0) counts[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 * MH * 32 + (wave * MH + t) * 32 + lane] = c;
+    }
+}
+
+// ---- overlap diagnostics: ROLE 0 = the two MFMAs per step only (accumulating, results kept live), ROLE 1 = the 1.5-op
+// epilogue only (on fixed registers), ROLE 2 = 512-thread workgroup, waves 0-3 MFMA-only and waves 4-7 VALU-only (two
+// waves per SIMD, one of each kind), ROLE 3 = both in every wave (same as PIPE 4, accumulating MFMAs)
+template <int MH, int ROLE>
+__global__ __launch_bounds__(ROLE == 2 ? 512 : 256) void k_diag(const float* __restrict__ hyp, const float* __restrict__ pixc,
+                                                                 int* __restrict__ counts, int ntiles, int reps) {
+    extern __shared__ __attribute__((aligned(16))) u16 lds[];
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, half = lane >> 5;
+    const int kind = ROLE == 2 ? (threadIdx.x >> 8) : ROLE;  // 0 mfma, 1 valu, 3 both
+    stage_pixels(pixc + (size_t)blockIdx.y * ntiles * 32 * 6, ntiles * 32, lds);
+    bf16x8 B[MH];
+    unsigned ucnt[MH];
+#pragma unroll
+    for (int t = 0; t < MH; ++t) {
+        const int j = (wave * MH + t) * 32 + (lane & 31);
+        B[t] = make_b(hyp[j * 2], hyp[j * 2 + 1], half);
+        ucnt[t] = 0u;
+    }
+    __syncthreads();
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const char* lbase = reinterpret_cast<const char*>(lds) + (lane & 31) * 32 + half * 16;
+    bf16x8 Acr = *reinterpret_cast<const bf16x8*>(lbase), Ad = *reinterpret_cast<const bf16x8*>(lbase + 1024);
+    f32x16 cr[2], d[2];
+    cr[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Acr, B[0], zero, 0, 0, 0);
+    d[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ad, B[0], zero, 0, 0, 0);
+    cr[1] = cr[0]; d[1] = d[0];
+    for (int r = 0; r < reps; ++r) {
+        for (int tile = 0; tile < ntiles; ++tile) {
+            const int nt = tile + 1 < ntiles ? tile + 1 : tile;
+            const bf16x8 Ncr = *reinterpret_cast<const bf16x8*>(lbase + nt * TILE_BYTES);
+            const bf16x8 Nd = *reinterpret_cast<const bf16x8*>(lbase + nt * TILE_BYTES + 1024);
+#pragma unroll
+            for (int t = 0; t < MH; ++t) {
+                f32x16& c0 = cr[t & 1];
+                f32x16& d0 = d[t & 1];
+                if (kind != 1) c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Acr : Ncr, B[(t + 1) % MH], kind == 3 ? zero : c0, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16& c1 = cr[(t + 1) & 1];
+                f32x16& d1 = d[(t + 1) & 1];
+                if (kind != 0) vote8i(ucnt[t], d1[0], c1[0], d1[1], c1[1], d1[2], c1[2], d1[3], c1[3], d1[4], c1[4], d1[5], c1[5], d1[6], c1[6], d1[7], c1[7]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kind != 1) d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Ad : Nd, B[(t + 1) % MH], kind == 3 ? zero : d0, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kind != 0) vote8i(ucnt[t], d1[8], c1[8], d1[9], c1[9], d1[10], c1[10], d1[11], c1[11], d1[12], c1[12], d1[13], c1[13], d1[14], c1[14], d1[15], c1[15]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            Acr = Ncr;
+            Ad = Nd;
+        }
+    }
+    float keep = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) keep += cr[0][i] + cr[1][i] + d[0][i] + d[1][i];
+#pragma unroll
+    for (int t = 0; t < MH; ++t) {
+        const int ci = (int)(((ucnt[t] >> 23) * 383u) & 511u) + (keep == 12345.f);
+        if (half == 0 && kind != 0 || keep == 54321.f) counts[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 * MH * 32 + (wave * MH + t) * 32 + (lane & 31)] = ci;
     }
 }
 
@@ -295,6 +390,21 @@ int main() {
     }
     printf("layout check: %d hypotheses x %d pixels, %ld votes expected, %ld hypotheses differ (sum |diff| %ld)\n", nh, npix,
            tot, bad, flips);
+    {   // clamp-vote variants need the 2^90 record scaling: check them on scaled pixel constants
+        std::vector<float> pix2(pix);
+        for (auto& x : pix2) x *= 0x1p90f;
+        hipMemcpy(dp, pix2.data(), pix2.size() * 4, hipMemcpyHostToDevice);
+        for (int variant = 3; variant <= 4; ++variant) {
+            if (variant == 3) hipLaunchKernelGGL((k_mfma_vote2<MH, 3>), dim3(1, 1), dim3(256), ntiles * TILE_BYTES, 0, dh, dp, dc, ntiles, 1);
+            else hipLaunchKernelGGL((k_mfma_vote2<MH, 4>), dim3(1, 1), dim3(256), ntiles * TILE_BYTES, 0, dh, dp, dc, ntiles, 1);
+            std::vector<int> g2(nh);
+            hipMemcpy(g2.data(), dc, nh * 4, hipMemcpyDeviceToHost);
+            int nb = 0;
+            for (int j = 0; j < nh; ++j) nb += g2[j] != got[j];
+            printf("clamp-vote variant %d (2^90-scaled records): %d hypotheses differ from the compare kernel\n", variant, nb);
+        }
+        hipMemcpy(dp, pix.data(), pix.size() * 4, hipMemcpyHostToDevice);
+    }
     for (int variant = 0; variant < 3; ++variant) {
         if (variant == 0) hipLaunchKernelGGL((k_mfma_vote2<MH, 0>), dim3(1, 1), dim3(256), ntiles * TILE_BYTES, 0, dh, dp, dc, ntiles, 1);
         else if (variant == 1) hipLaunchKernelGGL((k_mfma_vote2<MH, 1>), dim3(1, 1), dim3(256), ntiles * TILE_BYTES, 0, dh, dp, dc, ntiles, 1);
@@ -322,12 +432,13 @@ int main() {
         ms /= 5;
         const double tests = (double)g.x * nh * npix * reps;
         printf("waves/SIMD %d  bf16x3 mfma vote (MH=%d): %8.3f ms  %7.2f Tpairs/s\n", wpc, MH, ms, tests / ms / 1e9);
-        for (int variant = 0; variant < 4; ++variant) {
+        for (int variant = 0; variant < 5; ++variant) {
             auto launch = [&] {
                 if (variant == 0) hipLaunchKernelGGL((k_mfma_vote2<MH, 0>), g, b, ntiles * TILE_BYTES, 0, dh, dp, dc, ntiles, reps);
                 else if (variant == 1) hipLaunchKernelGGL((k_mfma_vote2<MH, 1>), g, b, ntiles * TILE_BYTES, 0, dh, dp, dc, ntiles, reps);
                 else if (variant == 2) hipLaunchKernelGGL((k_mfma_vote2<MH, 2>), g, b, ntiles * TILE_BYTES, 0, dh, dp, dc, ntiles, reps);
-                else hipLaunchKernelGGL((k_mfma_vote2<MH, 3>), g, b, ntiles * TILE_BYTES, 0, dh, dp, dc, ntiles, reps);
+                else if (variant == 3) hipLaunchKernelGGL((k_mfma_vote2<MH, 3>), g, b, ntiles * TILE_BYTES, 0, dh, dp, dc, ntiles, reps);
+                else hipLaunchKernelGGL((k_mfma_vote2<MH, 4>), g, b, ntiles * TILE_BYTES, 0, dh, dp, dc, ntiles, reps);
             };
             launch();
             hipDeviceSynchronize();
@@ -337,7 +448,25 @@ int main() {
             hipEventSynchronize(e1);
             hipEventElapsedTime(&ms, e0, e1);
             ms /= 5;
-            printf("waves/SIMD %d    asm epilogue%s: %8.3f ms  %7.2f Tpairs/s\n", wpc, variant == 3 ? " float clamp, interleaved" : variant == 2 ? " + interleaved" : variant ? " + pipelined  " : "              ", ms, tests / ms / 1e9);
+            printf("waves/SIMD %d    asm epilogue%s: %8.3f ms  %7.2f Tpairs/s\n", wpc, variant == 4 ? " clamp + add3 (1.5 op), interleaved" : variant == 3 ? " float clamp, interleaved" : variant == 2 ? " + interleaved" : variant ? " + pipelined  " : "              ", ms, tests / ms / 1e9);
+        }
+        for (int role = 0; role < 4; ++role) {
+            auto launch = [&] {
+                if (role == 0) hipLaunchKernelGGL((k_diag<MH, 0>), g, b, ntiles * TILE_BYTES, 0, dh, dp, dc, ntiles, reps);
+                else if (role == 1) hipLaunchKernelGGL((k_diag<MH, 1>), g, b, ntiles * TILE_BYTES, 0, dh, dp, dc, ntiles, reps);
+                else if (role == 2) hipLaunchKernelGGL((k_diag<MH, 2>), g, dim3(512), ntiles * TILE_BYTES, 0, dh, dp, dc, ntiles, reps);
+                else hipLaunchKernelGGL((k_diag<MH, 3>), g, b, ntiles * TILE_BYTES, 0, dh, dp, dc, ntiles, reps);
+            };
+            launch();
+            hipDeviceSynchronize();
+            hipEventRecord(e0);
+            for (int i = 0; i < 5; ++i) launch();
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+            ms /= 5;
+            printf("waves/SIMD %d    diag %s: %8.3f ms  %7.2f Tpairs/s-equivalent\n", role == 2 ? 2 * wpc : wpc,
+                   role == 0 ? "MFMA only            " : role == 1 ? "VALU (1.5 op) only    " : role == 2 ? "MFMA waves + VALU waves (512 thr)" : "both in every wave    ", ms, tests / ms / 1e9);
         }
     }
     return 0;
