@@ -19,7 +19,7 @@ Besides the contract's fields the line carries
                 `achieved` = the matrix flops executed for the algorithmic hn*vn*tn pair tests (2 MFMAs per
                 32x32 tests = 64 flop per test) over the kernel's duration, `peak` = 2.5 PFLOP/s dense bf16;
                 `algorithmic` restates it with SURVEY.md 8d's 12 fp32 flop per test against the 157.3 TFLOP/s
-                fp32 vector peak, `issue_bound` against what the SIMD can issue (64 MFMA + 64 VALU cycles per
+                fp32 vector peak, `issue_bound` against what the SIMD can issue (64 MFMA + 48 VALU cycles per
                 1024 tests).  Duration measured live with hipEvents on the op's stream (pvnet_vote_v3_profiled).
   roofline_hbm  the whole path against the HBM roofline: algorithmic bytes (24 576 072 B per voting with the
                 int64 mask) x votings / time of all seven launches, peak 8 TB/s.
@@ -49,7 +49,7 @@ PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = f32 MFMA dense peak
 PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16: 32 cycles per SIMD)
 MFMA_FLOP_PER_PAIR = 2 * (2 * 32 * 32 * 16) / (32 * 32)  # two 32x32x16 MFMAs (cr, dt) per 32x32 pair tests = 64
-ISSUE_CYCLES_PER_1024 = 2 * 32 + 32 * 2  # 2 MFMAs x 32 cycles + 32 VALU (2 per test per lane) x 2 cycles, per SIMD
+ISSUE_CYCLES_PER_1024 = 2 * 32 + 24 * 2  # 2 MFMAs x 32 cycles + 24 VALU (1.5 per test per lane) x 2 cycles, per SIMD
 PEAK_CLOCK_HZ = 2.4e9
 N_SIMD = 256 * 4
 
@@ -166,7 +166,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    # under torch.distributed.run (RANK + MASTER_ADDR set) the process group and the key-point all-gather are used at
+    # any world size, so that a 1-rank launch exercises exactly the code path the N-rank launches run
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
         import torch.distributed as dist_mod
         dist = dist_mod
         torch.cuda.set_device(local)
@@ -183,7 +185,7 @@ def main():
     nstreams = max(1, a.streams)
     streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
     gathered = [torch.empty((world * BATCH, VN, 2), dtype=torch.float32, device=dev) for _ in range(nstreams + 1)] \
-        if world > 1 else None
+        if dist is not None else None
     pending = []
 
     def step(i, ns=nstreams, **kw):
@@ -194,7 +196,7 @@ def main():
         with torch.cuda.stream(streams[i % ns]):
             out = voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=1234 + i,
                                                 image_offset=rank * BATCH)
-            if world > 1:
+            if dist is not None:
                 # the path's single exchange: RCCL all-gather of the [32, 9, 2] key-points over xGMI
                 pending.append(dist.all_gather_into_tensor(gathered[i % (nstreams + 1)], out, async_op=True))
                 if len(pending) > ns:
@@ -205,7 +207,7 @@ def main():
         while pending:
             pending.pop(0).wait()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -218,7 +220,7 @@ def main():
             step(i, ns)
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -284,7 +286,7 @@ def main():
                                          "frac": pairs / score_s / (1024 / ISSUE_CYCLES_PER_1024 * PEAK_CLOCK_HZ * N_SIMD)},
                          "note": "each pair test = two 3-term fp32 dot products + compare; operands split into three "
                                  "bf16 parts, six part products kept per product (K = 15 of 16), fp32 accumulation on "
-                                 "the matrix pipe; 2 VALU ops per test count the votes.  Matrix and vector issue do "
+                                 "the matrix pipe; 1.5 VALU ops per test count the votes.  Matrix and vector issue do "
                                  "not overlap within a SIMD for this mix (tools/ubench_mfma.hip), hence issue_bound"},
             "roofline_hbm": {"bound": "hbm", "achieved": BYTES_PER_VOTING * BATCH / path_s / 1e9,
                              "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -296,7 +298,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sets, a.cpu_seconds)
         print(json.dumps(res))
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -747,8 +747,11 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
         bf16x8 Acr = __builtin_bit_cast(bf16x8, lbase[0]), Adt = __builtin_bit_cast(bf16x8, lbase[64]);
         f32x16 cr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Acr, B[0], zero, 0, 0, 0);
         f32x16 dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Adt, B[0], zero, 0, 0, 0);
-        for (int tile = 0; tile < ntiles; ++tile) {
-            const int nt = tile + 1 < ntiles ? tile + 1 : tile;  // (after the last tile: a harmless repeat)
+        // the image's last pixel group is usually partial: tiles beyond the padded pixel count hold only zero rows
+        const int left = (tpad - cg * npx + 31) >> 5;
+        const int nti = left < ntiles ? left : ntiles;
+        for (int tile = 0; tile < nti; ++tile) {
+            const int nt = tile + 1 < nti ? tile + 1 : tile;  // (after the last tile: a harmless repeat)
             const bf16x8 Ncr = __builtin_bit_cast(bf16x8, lbase[nt * TILE_U4]);
             const bf16x8 Ndt = __builtin_bit_cast(bf16x8, lbase[nt * TILE_U4 + 64]);
 #pragma unroll
