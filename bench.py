@@ -7,8 +7,9 @@
 
 A "step" is one pass of the whole voting path (mask + 9-key-point vector field -> 9 key-points) over one
 batch of 32 synthetic images per GPU, inputs resident in HBM.  Steps are independent batches, so they are issued
-round-robin on --streams HIP streams (default 4): the matrix-pipe scoring kernel holds 12 of a CU's 32 wave slots
-and the next batch's small latency-bound stages run beside it; `single_stream` in the output is the same K steps
+round-robin on --streams HIP streams (default 6; measured 1/2/3/4/5/6/8/12/16 streams -> 0.143/0.118/0.113/0.122/
+0.115/0.112/0.115/0.114/0.114 ms per batch, profiles/r01_streams_probe.txt): the matrix-pipe scoring kernel holds
+12 of a CU's 32 wave slots and the next batches' small latency-bound stages run beside it; `single_stream` in the output is the same K steps
 issued strictly one after the other.  With N > 1 every rank votes its own 32 images
 (weak scaling, no data-path collective) and the step ends with the path's one real exchange: an RCCL
 all-gather of the [32, 9, 2] key-points.  Rank 0 prints ONE JSON line.
@@ -65,7 +66,7 @@ def parse():
     ap.add_argument("--radius", type=int, default=40, help="disk radius of the synthetic object mask (tn ~ pi r^2)")
     ap.add_argument("--buffers", type=int, default=2, help="distinct input sets cycled (2 x 786 MB > 256 MiB L3)")
     ap.add_argument("--clean", action="store_true", help="noise-free field (default: noisy, net-like background)")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=6,
                     help="HIP streams the steps are issued on round-robin (independent batches in flight; the scoring "
                          "kernel keeps 12 of a CU's 32 wave slots, so the next batch's small stages run beside it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -162,6 +163,11 @@ def cpu_baseline(sets, seconds):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE JSON line: RCCL prints a version banner to stdout when its communicator comes up, so
+    # fd 1 is pointed at stderr for the run and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -297,7 +303,8 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sets, a.cpu_seconds)
-        print(json.dumps(res))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

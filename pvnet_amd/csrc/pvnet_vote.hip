@@ -51,7 +51,20 @@ constexpr int CTRL_STRIDE = 8;
 enum { C_TN0 = 0, C_TN = 1, C_STATUS = 2, C_ITEM_BASE = 3, C_NCHUNKS = 4, C_OX = 5, C_OY = 6 };
 
 constexpr int SEG_WORDS = 64;          // a segment = 64 words = 4096 pixels: the unit of K1 / K1b / K2 workgroups
-constexpr int K1_WAVES = 16;            // waves per K1 workgroup (one workgroup = one segment): measured 4 -> 22.5 us,
+#ifndef PVNET_K1_WAVES
+#define PVNET_K1_WAVES 16
+#endif
+#ifndef PVNET_RT
+#define PVNET_RT 512
+#endif
+#ifndef PVNET_SMALL_PRIO
+#define PVNET_SMALL_PRIO 0
+#endif
+// the small latency-bound stages may ask for issue priority over the co-resident scoring waves of other batches
+__device__ __forceinline__ void small_stage_prio() {
+    if (PVNET_SMALL_PRIO) __builtin_amdgcn_s_setprio(PVNET_SMALL_PRIO);
+}
+constexpr int K1_WAVES = PVNET_K1_WAVES;  // waves per K1 workgroup (one workgroup = one segment): measured 4 -> 22.5 us,
                                         // 8 -> 20.6 us, 16 -> 19.4 us for the 78.6 MB int64 masks of a batch of 32
 constexpr int K1B_WAVES = 4;            // K1b (usually a no-op): small workgroups,
 constexpr int K1B_BLOCKS = 8;           // ... at least this many per image (more for small batches), each walking
@@ -237,6 +250,7 @@ __device__ __forceinline__ bool load_fg(const void* m, int64_t off) {
 
 template <int DT>
 __global__ __launch_bounds__(64 * K1_WAVES) void mask_bits_kernel(VoteParams P) {
+    small_stage_prio();
     const int bi = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int word0 = (blockIdx.x * K1_WAVES + wave) * K1_WORDS_PER_WAVE;
@@ -290,6 +304,7 @@ __global__ __launch_bounds__(64 * K1_WAVES) void mask_bits_kernel(VoteParams P) 
 // K1b: Bernoulli subsample when tn0 > max_num                 (ransac_voting_gpu.py:537-540)
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * K1B_WAVES) void subsample_kernel(VoteParams P) {
+    small_stage_prio();
     const int bi = blockIdx.y;
     // tn0 = sum of this image's segment counts as K1 wrote them (seg0: blocks of this launch rewrite only seg).
     // Every wave reduces it for itself: no barrier, no atomics.  K1B_BLOCKS blocks per image: in the common case
@@ -334,6 +349,7 @@ __global__ __launch_bounds__(64 * K1B_WAVES) void subsample_kernel(VoteParams P)
 // ------------------------------------------------------------------------------------------------------------
 template <bool LITERAL, int K2_KG>  // K2_KG key-points per block: grid.z = ceil(vn / K2_KG)
 __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
+    small_stage_prio();
     const int bi = blockIdx.y;
     const int w0 = blockIdx.x * K2_WORDS_PER_BLOCK;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -501,6 +517,7 @@ __device__ __forceinline__ void plan_image(const VoteParams& P, int bi) {
 // ------------------------------------------------------------------------------------------------------------
 template <bool LITERAL>
 __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
+    small_stage_prio();
     // Workgroups go to the 8 XCDs round-robin by linear id; every block of image bi is placed on XCD bi % 8 so that
     // the two random 16-byte record reads per hypothesis (several per 128-byte line of the image's records) hit
     // that XCD's L2 after the first touch instead of crossing the fabric once per XCD.
@@ -786,10 +803,11 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
 // ------------------------------------------------------------------------------------------------------------
 // K5: arg-max + least-squares refinement                        (ransac_voting_gpu.py:561-569, 579-595, 503-512)
 // ------------------------------------------------------------------------------------------------------------
-constexpr int RT = 512;  // threads per (image, key-point) (measured: 256 -> 19 us, 1024 -> 23 us at batch 32)
+constexpr int RT = PVNET_RT;  // threads per (image, key-point) (measured: 256 -> 19 us, 1024 -> 23 us at batch 32)
 constexpr int RW = RT / 64;
 template <bool LITERAL>
 __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
+    small_stage_prio();
     const int k = blockIdx.x, bi = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t bk = (size_t)bi * P.vn + k;
@@ -1089,10 +1107,14 @@ int launch_score(const VoteParams& P, dim3 grid, hipStream_t s) {
 int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
     const bool literal = (P.flags & PVNET_F_LITERAL) != 0;
     auto mark = [&](int i) -> hipError_t { return ev ? hipEventRecord(ev[i], s) : hipSuccess; };
+    // development aid (tools/overlap_probe.py): bit i set = launch stage i (K1, K1b, K2, K3, K4, K5); a workspace
+    // left by a complete call stays valid, so single stages can be re-run on it in isolation
+    const int stages = env_int("PVNET_DEV_STAGES", 0x3F);
     PV_HIP(mark(0));
     {   // K1
         dim3 grid(P.nseg, P.b);
-        switch (P.mask_dtype) {
+        switch ((stages & 1) ? P.mask_dtype : -1) {
+            case -1: break;
             case PVNET_MASK_U8: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_U8>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
             case PVNET_MASK_I16: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I16>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
             case PVNET_MASK_I32: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I32>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
@@ -1103,7 +1125,7 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
         }
         PV_LAUNCH_CHECK();
         PV_HIP(mark(1));
-        if (P.max_num < P.npix) {  // host-known: subsampling can only trigger when max_num < h*w
+        if ((stages & 2) && P.max_num < P.npix) {  // host-known: subsampling can only trigger when max_num < h*w
             int bpi = (640 + P.b - 1) / P.b;  // blocks per image: a few hundred blocks in total, whatever the batch
             bpi = bpi < K1B_BLOCKS ? K1B_BLOCKS : bpi;
             bpi = bpi > P.nseg ? P.nseg : bpi;
@@ -1112,7 +1134,7 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
         }
         PV_HIP(mark(2));
     }
-    {   // K2
+    if (stages & 4) {   // K2
         const int kg = env_int("PVNET_COMPACT_KG", 3);
         dim3 grid(P.nseg, P.b, (P.vn + kg - 1) / kg);
         if (literal) hipLaunchKernelGGL((compact_kernel<true, 3>), dim3(P.nseg, P.b, (P.vn + 2) / 3), dim3(256), 0, s, P);
@@ -1120,16 +1142,16 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
         else if (kg == 9) hipLaunchKernelGGL((compact_kernel<false, 9>), grid, dim3(256), 0, s, P);
         else hipLaunchKernelGGL((compact_kernel<false, 3>), dim3(P.nseg, P.b, (P.vn + 2) / 3), dim3(256), 0, s, P);
         PV_LAUNCH_CHECK();
-        PV_HIP(mark(3));
     }
-    {   // K3
+    PV_HIP(mark(3));
+    if (stages & 8) {   // K3
         dim3 grid((unsigned)(((P.hn * P.vn + 255) / 256 + 1) * ((P.b + 7) / 8) * 8));
         if (literal) hipLaunchKernelGGL(hypothesis_kernel<true>, grid, dim3(256), 0, s, P);
         else hipLaunchKernelGGL(hypothesis_kernel<false>, grid, dim3(256), 0, s, P);
         PV_LAUNCH_CHECK();
-        PV_HIP(mark(4));
     }
-    {   // K4: persistent grid, work items strided over its waves
+    PV_HIP(mark(4));
+    if (stages & 16) {   // K4: persistent grid, work items strided over its waves
         const long long max_items =
             (long long)P.b * P.vn * (P.hgroups / P.wg_g) * ((P.max_chunks + P.wg_s - 1) / P.wg_s);
         const int wgs_per_cu = env_int("PVNET_SCORE_WGS_PER_CU", 8);
@@ -1151,15 +1173,15 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
             if (rc) return rc;
         }
         PV_LAUNCH_CHECK();
-        PV_HIP(mark(5));
     }
-    {   // K5
+    PV_HIP(mark(5));
+    if (stages & 32) {   // K5
         dim3 grid(P.vn, P.b);
         if (literal) hipLaunchKernelGGL(select_refine_kernel<true>, grid, dim3(RT), 0, s, P);
         else hipLaunchKernelGGL(select_refine_kernel<false>, grid, dim3(RT), 0, s, P);
         PV_LAUNCH_CHECK();
-        PV_HIP(mark(6));
     }
+    PV_HIP(mark(6));
     return 0;
 }
 

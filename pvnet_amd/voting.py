@@ -48,10 +48,11 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"pvnet_amd: HIP library {LIB_PATH} is missing -- build it with "
+    lib_path = os.environ.get("PVNET_VOTE_LIB", LIB_PATH)  # development aid: an experimental build of the same ABI
+    if not os.path.exists(lib_path):
+        raise RuntimeError(f"pvnet_amd: HIP library {lib_path} is missing -- build it with "
                            f"`python -m pvnet_amd.build` (hipcc, gfx950). There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(lib_path)
     i64p, f32p, i32p, u8p = C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p
     lib.pvnet_vote_abi_version.restype = C.c_int
     lib.pvnet_vote_build_info.restype = C.c_char_p
