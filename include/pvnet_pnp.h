@@ -1,0 +1,42 @@
+/* pvnet_pnp.h -- C ABI of the host-side pose refinement (libpvnet_pnp.so, plain C++, no GPU, no dependencies).
+ *
+ * the reference solves the 9-point pose problem on the host too --
+ *   - `uncertainty_pnp`  (lib/utils/extend_utils/src/uncertainty_pnp.cpp:61-92, bound through cffi at
+ *                         lib/utils/extend_utils/extend_utils.py:63-114): Ceres Levenberg-Marquardt (DENSE_SCHUR,
+ *                         default options) on the 2x2-weighted reprojection residuals of uncertainty_pnp.cpp:18-35,
+ *                         pose = (angle-axis[3], translation[3]);
+ *   - `pnp`              (lib/utils/evaluation_utils.py:19-52): cv2.solvePnP(..., SOLVEPNP_ITERATIVE), i.e. the same
+ *                         Levenberg-Marquardt on unweighted residuals after a linear start.
+ * Neither Ceres nor OpenCV exists in this image, and the problem is 2*pn residuals x 6 parameters: a dense LM with
+ * analytic Jacobians in ~200 lines.  `uncertainty_pnp` below keeps the reference's name, argument order and meaning
+ * (uncertainty_pnp.cpp:61-69), so the reference's cffi `lib.uncertainty_pnp(...)` call binds to it unchanged.
+ */
+#ifndef PVNET_PNP_H_
+#define PVNET_PNP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Reference signature (uncertainty_pnp.cpp:61-69).  All pointers are host pointers to contiguous doubles.
+ *   pts2d [pn,2], pts3d [pn,3], wgt2d [pn,3] = (wxx, wxy, wyy) of the symmetric 2x2 weight per point,
+ *   K [3,3] row-major (fx = K[0], fy = K[4], px = K[2], py = K[5]), init_rt [6] = angle-axis + translation,
+ *   result_rt [6] receives the refined pose.  Like the reference it returns nothing; a failed solve leaves the best
+ *   iterate (at worst init_rt) in result_rt. */
+void uncertainty_pnp(double* pts2d, double* pts3d, double* wgt2d, double* K, double* init_rt, double* result_rt,
+                     int pn);
+
+/* The same solver with a report.  wgt2d may be NULL (identity weights = the unweighted reprojection error that
+ * cv2.solvePnP's ITERATIVE flag minimises).  Returns the number of LM iterations taken (>= 0), or -1 on bad
+ * arguments.  final_cost (may be NULL) receives 0.5 * sum of squared weighted residuals. */
+int pvnet_pnp_refine(const double* pts2d, const double* pts3d, const double* wgt2d, const double* K,
+                     const double* init_rt, double* result_rt, int pn, int max_iterations, double* final_cost);
+
+/* angle-axis <-> rotation matrix (cv2.Rodrigues / ceres::AngleAxisToRotationMatrix), row-major R[9] */
+void pvnet_angle_axis_to_matrix(const double* aa, double* R);
+void pvnet_matrix_to_angle_axis(const double* R, double* aa);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVNET_PNP_H_ */

@@ -17,6 +17,10 @@ SRC = [os.path.join(HERE, "csrc", "pvnet_vote.hip")]
 DEPS = SRC + [os.path.join(HERE, "csrc", "pvnet_rng.h"), os.path.join(ROOT, "include", "pvnet_vote.h")]
 LIB = os.path.join(HERE, "libpvnet_vote.so")
 ARCH = "gfx950"
+# host-side pose refinement (plain C++, g++): include/pvnet_pnp.h
+PNP_SRC = os.path.join(HERE, "csrc", "pvnet_pnp.cpp")
+PNP_DEPS = [PNP_SRC, os.path.join(ROOT, "include", "pvnet_pnp.h")]
+PNP_LIB = os.path.join(HERE, "libpvnet_pnp.so")
 
 
 def hipcc_path() -> str:
@@ -37,7 +41,22 @@ def up_to_date() -> bool:
     return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS)
 
 
+def build_pnp(force: bool = False, verbose: bool = False) -> str:
+    if not force and os.path.exists(PNP_LIB) and all(os.path.getmtime(PNP_LIB) >= os.path.getmtime(d) for d in PNP_DEPS):
+        return PNP_LIB
+    cxx = os.environ.get("CXX") or shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        raise RuntimeError("no C++ compiler found for libpvnet_pnp.so (set CXX)")
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"), PNP_SRC,
+           "-o", PNP_LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return PNP_LIB
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    build_pnp(force, verbose)
     if not force and up_to_date():
         return LIB
     cmd = [hipcc_path()] + flags() + SRC + ["-o", LIB]

@@ -1,0 +1,236 @@
+// libpvnet_pnp.so -- host-side pose refinement for the voted key-points (include/pvnet_pnp.h).
+//
+// What it replaces: the Ceres problem of lib/utils/extend_utils/src/uncertainty_pnp.cpp:61-92 (one 2-residual block per
+// key-point, residual = W * (project(R(aa) X + t) - x), uncertainty_pnp.cpp:18-35) and, with identity weights, the
+// Levenberg-Marquardt stage of cv2.solvePnP(SOLVEPNP_ITERATIVE) behind lib/utils/evaluation_utils.py:19-52.
+// Dense LM on the 6 pose parameters (angle-axis, translation) with analytic Jacobians; 2*pn x 6 with pn = 9.
+// Plain C++17, no dependencies; built by pvnet_amd/build.py with g++.
+#include "pvnet_pnp.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+void cross_matrix(const double* v, double* M) {  // [v]x, row-major
+    M[0] = 0; M[1] = -v[2]; M[2] = v[1];
+    M[3] = v[2]; M[4] = 0; M[5] = -v[0];
+    M[6] = -v[1]; M[7] = v[0]; M[8] = 0;
+}
+void matmul3(const double* A, const double* B, double* C) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+
+// R = exp([w]x) and the right Jacobian Jr(w) of SO(3): R(w + d) = R(w) exp([Jr d]x) + O(d^2)
+void rotation_and_right_jacobian(const double* w, double* R, double* Jr) {
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = std::sqrt(th2);
+    double a, b, c;  // sin(th)/th, (1 - cos th)/th^2, (th - sin th)/th^3
+    if (th < 1e-5) {  // series: accurate to O(th^4)
+        a = 1.0 - th2 / 6.0;
+        b = 0.5 - th2 / 24.0;
+        c = 1.0 / 6.0 - th2 / 120.0;
+    } else {
+        a = std::sin(th) / th;
+        b = (1.0 - std::cos(th)) / th2;
+        c = (th - std::sin(th)) / (th2 * th);
+    }
+    double Wx[9], W2[9];
+    cross_matrix(w, Wx);
+    matmul3(Wx, Wx, W2);
+    for (int i = 0; i < 9; ++i) {
+        const double I = (i % 4 == 0) ? 1.0 : 0.0;
+        R[i] = I + a * Wx[i] + b * W2[i];
+        if (Jr) Jr[i] = I - b * Wx[i] + c * W2[i];
+    }
+}
+
+struct Problem {
+    const double *x2, *x3, *wgt, *K;
+    int pn;
+};
+
+// residuals r[2 pn] and (optionally) Jacobian J[2 pn][6] at pose p; false if a point falls on / behind the camera plane
+bool evaluate(const Problem& P, const double* p, double* r, double* J) {
+    double R[9], Jr[9];
+    rotation_and_right_jacobian(p, R, J ? Jr : nullptr);
+    const double fx = P.K[0], fy = P.K[4], px = P.K[2], py = P.K[5];
+    for (int i = 0; i < P.pn; ++i) {
+        const double* X = P.x3 + 3 * i;
+        const double RX[3] = {R[0] * X[0] + R[1] * X[1] + R[2] * X[2], R[3] * X[0] + R[4] * X[1] + R[5] * X[2],
+                              R[6] * X[0] + R[7] * X[1] + R[8] * X[2]};
+        const double Y[3] = {RX[0] + p[3], RX[1] + p[4], RX[2] + p[5]};
+        if (!(std::fabs(Y[2]) > 1e-12)) return false;
+        const double iz = 1.0 / Y[2];
+        const double dx = fx * Y[0] * iz + px - P.x2[2 * i], dy = fy * Y[1] * iz + py - P.x2[2 * i + 1];
+        double wxx = 1.0, wxy = 0.0, wyy = 1.0;
+        if (P.wgt) { wxx = P.wgt[3 * i]; wxy = P.wgt[3 * i + 1]; wyy = P.wgt[3 * i + 2]; }
+        r[2 * i] = wxx * dx + wxy * dy;          // uncertainty_pnp.cpp:29-30
+        r[2 * i + 1] = wxy * dx + wyy * dy;
+        if (!J) continue;
+        // d(proj)/dY (2x3), dY/dt = I, dY/dw = -R [X]x Jr
+        const double A[6] = {fx * iz, 0.0, -fx * Y[0] * iz * iz, 0.0, fy * iz, -fy * Y[1] * iz * iz};
+        double Xx[9], RXx[9], D[9];
+        cross_matrix(X, Xx);
+        matmul3(R, Xx, RXx);
+        matmul3(RXx, Jr, D);
+        double Jp[12];  // unweighted 2x6
+        for (int c = 0; c < 3; ++c) {
+            Jp[c] = -(A[0] * D[c] + A[1] * D[3 + c] + A[2] * D[6 + c]);
+            Jp[6 + c] = -(A[3] * D[c] + A[4] * D[3 + c] + A[5] * D[6 + c]);
+            Jp[3 + c] = A[c];
+            Jp[9 + c] = A[3 + c];
+        }
+        for (int c = 0; c < 6; ++c) {
+            J[(2 * i) * 6 + c] = wxx * Jp[c] + wxy * Jp[6 + c];
+            J[(2 * i + 1) * 6 + c] = wxy * Jp[c] + wyy * Jp[6 + c];
+        }
+    }
+    return true;
+}
+
+// solve the symmetric positive definite 6x6 system A x = b by Cholesky; false if A is not positive definite
+bool solve6(const double* A, const double* b, double* x) {
+    double L[36];
+    std::memset(L, 0, sizeof(L));
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
+            if (i == j) {
+                if (!(s > 0.0) || !std::isfinite(s)) return false;
+                L[i * 6 + i] = std::sqrt(s);
+            } else {
+                L[i * 6 + j] = s / L[j * 6 + j];
+            }
+        }
+    double y[6];
+    for (int i = 0; i < 6; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k];
+        y[i] = s / L[i * 6 + i];
+    }
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+        for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k];
+        x[i] = s / L[i * 6 + i];
+    }
+    return true;
+}
+
+constexpr int MAX_PN = 4096;
+
+}  // namespace
+
+extern "C" {
+
+int pvnet_pnp_refine(const double* pts2d, const double* pts3d, const double* wgt2d, const double* K,
+                     const double* init_rt, double* result_rt, int pn, int max_iterations, double* final_cost) {
+    if (!pts2d || !pts3d || !K || !init_rt || !result_rt || pn < 3 || pn > MAX_PN) return -1;
+    if (max_iterations <= 0) max_iterations = 100;
+    const Problem P{pts2d, pts3d, wgt2d, K, pn};
+    double* r = new double[2 * pn];
+    double* rn = new double[2 * pn];
+    double* J = new double[12 * pn];
+    double p[6], pnw[6];
+    std::memcpy(p, init_rt, sizeof(p));
+    std::memcpy(result_rt, init_rt, sizeof(p));
+    auto cost_of = [&](const double* res) {
+        double c = 0;
+        for (int i = 0; i < 2 * pn; ++i) c += res[i] * res[i];
+        return 0.5 * c;
+    };
+    int it = 0;
+    double cost = 0.0;
+    if (evaluate(P, p, r, J)) {
+        cost = cost_of(r);
+        double lambda = 1e-4, nu = 2.0;  // Marquardt damping on diag(J^T J), Nielsen's update
+        for (; it < max_iterations; ++it) {
+            double H[36], g[6];
+            for (int a = 0; a < 6; ++a) {
+                g[a] = 0;
+                for (int i = 0; i < 2 * pn; ++i) g[a] -= J[i * 6 + a] * r[i];
+                for (int b = 0; b <= a; ++b) {
+                    double s = 0;
+                    for (int i = 0; i < 2 * pn; ++i) s += J[i * 6 + a] * J[i * 6 + b];
+                    H[a * 6 + b] = H[b * 6 + a] = s;
+                }
+            }
+            double gmax = 0;
+            for (int a = 0; a < 6; ++a) gmax = std::fmax(gmax, std::fabs(g[a]));
+            if (gmax < 1e-14) break;  // stationary
+            bool stepped = false, tiny = false;
+            for (int tries = 0; tries < 40 && !stepped; ++tries) {
+                double A[36], d[6];
+                std::memcpy(A, H, sizeof(A));
+                for (int a = 0; a < 6; ++a) A[a * 6 + a] += lambda * (H[a * 6 + a] > 1e-300 ? H[a * 6 + a] : 1.0);
+                if (solve6(A, g, d)) {
+                    double dn = 0, xn = 0;
+                    for (int a = 0; a < 6; ++a) { pnw[a] = p[a] + d[a]; dn += d[a] * d[a]; xn += p[a] * p[a]; }
+                    if (std::sqrt(dn) <= 1e-15 * (std::sqrt(xn) + 1e-15)) { tiny = true; break; }
+                    if (evaluate(P, pnw, rn, nullptr)) {
+                        const double cn = cost_of(rn);
+                        double pred = 0;  // predicted decrease 0.5 d^T (lambda D d + g)
+                        for (int a = 0; a < 6; ++a)
+                            pred += 0.5 * d[a] * (lambda * (H[a * 6 + a] > 1e-300 ? H[a * 6 + a] : 1.0) * d[a] + g[a]);
+                        const double rho = pred > 0 ? (cost - cn) / pred : -1.0;
+                        if (cn < cost && rho > 0) {
+                            std::memcpy(p, pnw, sizeof(p));
+                            const double rel = (cost - cn) / (cost > 1e-300 ? cost : 1e-300);
+                            cost = cn;
+                            const double t = 2.0 * rho - 1.0;
+                            lambda *= std::fmax(1.0 / 3.0, 1.0 - t * t * t);
+                            nu = 2.0;
+                            stepped = true;
+                            if (rel < 1e-16) tiny = true;
+                            continue;
+                        }
+                    }
+                }
+                lambda *= nu;
+                nu *= 2.0;
+            }
+            if (!stepped || tiny) break;
+            if (!evaluate(P, p, r, J)) break;
+        }
+        std::memcpy(result_rt, p, sizeof(p));
+    }
+    if (final_cost) *final_cost = cost;
+    delete[] r;
+    delete[] rn;
+    delete[] J;
+    return it;
+}
+
+void uncertainty_pnp(double* pts2d, double* pts3d, double* wgt2d, double* K, double* init_rt, double* result_rt,
+                     int pn) {
+    if (pvnet_pnp_refine(pts2d, pts3d, wgt2d, K, init_rt, result_rt, pn, 100, nullptr) < 0 && init_rt && result_rt)
+        std::memcpy(result_rt, init_rt, 6 * sizeof(double));
+}
+
+void pvnet_angle_axis_to_matrix(const double* aa, double* R) { rotation_and_right_jacobian(aa, R, nullptr); }
+
+void pvnet_matrix_to_angle_axis(const double* R, double* aa) {
+    // robust log map: quaternion first (largest-component branch), then angle-axis
+    double q[4];  // w x y z
+    const double tr = R[0] + R[4] + R[8];
+    if (tr > 0) {
+        const double s = std::sqrt(tr + 1.0) * 2;
+        q[0] = 0.25 * s; q[1] = (R[7] - R[5]) / s; q[2] = (R[2] - R[6]) / s; q[3] = (R[3] - R[1]) / s;
+    } else if (R[0] > R[4] && R[0] > R[8]) {
+        const double s = std::sqrt(1.0 + R[0] - R[4] - R[8]) * 2;
+        q[0] = (R[7] - R[5]) / s; q[1] = 0.25 * s; q[2] = (R[1] + R[3]) / s; q[3] = (R[2] + R[6]) / s;
+    } else if (R[4] > R[8]) {
+        const double s = std::sqrt(1.0 + R[4] - R[0] - R[8]) * 2;
+        q[0] = (R[2] - R[6]) / s; q[1] = (R[1] + R[3]) / s; q[2] = 0.25 * s; q[3] = (R[5] + R[7]) / s;
+    } else {
+        const double s = std::sqrt(1.0 + R[8] - R[0] - R[4]) * 2;
+        q[0] = (R[3] - R[1]) / s; q[1] = (R[2] + R[6]) / s; q[2] = (R[5] + R[7]) / s; q[3] = 0.25 * s;
+    }
+    if (q[0] < 0) for (double& v : q) v = -v;
+    const double sn = std::sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const double k = sn < 1e-12 ? 2.0 : 2.0 * std::atan2(sn, q[0]) / sn;
+    aa[0] = k * q[1]; aa[1] = k * q[2]; aa[2] = k * q[3];
+}
+
+}  // extern "C"

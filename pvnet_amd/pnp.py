@@ -4,14 +4,67 @@ The reference does this on the host as well: ``pnp`` = ``cv2.solvePnP(..., SOLVE
 (lib/utils/evaluation_utils.py:19-52), ``uncertainty_pnp`` = P3P initialisation + a Ceres Levenberg-Marquardt on
 2x2-weighted reprojection residuals (lib/utils/extend_utils/extend_utils.py:63-114,
 lib/utils/extend_utils/src/uncertainty_pnp.cpp:7-92).  Neither OpenCV nor Ceres exists in this image, and this
-is a 9-point, 6-parameter problem: numpy + scipy.  Same algorithm class as OpenCV's ITERATIVE flag: a DLT
-initialisation followed by Levenberg-Marquardt on the reprojection error over (Rodrigues vector, translation).
+is a 9-point, 6-parameter problem.  Same algorithm class as OpenCV's ITERATIVE flag: a DLT initialisation (numpy)
+followed by Levenberg-Marquardt on the reprojection error over (Rodrigues vector, translation).  The LM is native:
+``libpvnet_pnp.so`` (pvnet_amd/csrc/pvnet_pnp.cpp, include/pvnet_pnp.h) exports the reference's own
+``uncertainty_pnp(pts2d, pts3d, wgt2d, K, init_rt, result_rt, pn)`` C signature, so the reference's cffi call binds to
+it unchanged; ``backend="scipy"`` runs the same problem through scipy's MINPACK LM (the cross-check the tests use).
 Also the pose metrics of ``Evaluator`` (evaluation_utils.py:75-134).  Not on the GPU hot path.
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
+
 import numpy as np
-from scipy.optimize import least_squares
+
+_PNP_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpvnet_pnp.so")
+_pnp_lib = None
+
+
+def load_pnp_library() -> C.CDLL:
+    """dlopen the in-tree host library; loud failure if it has not been built (python -m pvnet_amd.build)."""
+    global _pnp_lib
+    if _pnp_lib is None:
+        if not os.path.exists(_PNP_LIB_PATH):
+            raise RuntimeError(f"pvnet_amd: {_PNP_LIB_PATH} is missing -- build it with `python -m pvnet_amd.build`")
+        lib = C.CDLL(_PNP_LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        lib.uncertainty_pnp.restype = None
+        lib.uncertainty_pnp.argtypes = [dp] * 6 + [C.c_int]
+        lib.pvnet_pnp_refine.restype = C.c_int
+        lib.pvnet_pnp_refine.argtypes = [dp] * 6 + [C.c_int, C.c_int, dp]
+        lib.pvnet_angle_axis_to_matrix.restype = None
+        lib.pvnet_angle_axis_to_matrix.argtypes = [dp, dp]
+        lib.pvnet_matrix_to_angle_axis.restype = None
+        lib.pvnet_matrix_to_angle_axis.argtypes = [dp, dp]
+        _pnp_lib = lib
+    return _pnp_lib
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _refine(x0, points_3d, points_2d, K, W, backend):
+    """Levenberg-Marquardt on the (optionally 2x2-weighted) reprojection residuals from the pose vector x0[6]."""
+    if backend == "scipy":
+        from scipy.optimize import least_squares
+        return least_squares(_residuals, x0, args=(points_3d, points_2d, K, W), method="lm", xtol=1e-12, ftol=1e-12).x
+    if backend != "native":
+        raise ValueError(f"unknown backend {backend!r}")
+    lib = load_pnp_library()
+    p2 = np.ascontiguousarray(points_2d, np.float64)
+    p3 = np.ascontiguousarray(points_3d, np.float64)
+    Kc = np.ascontiguousarray(K, np.float64)
+    x0 = np.ascontiguousarray(x0, np.float64)
+    Wc = None if W is None else np.ascontiguousarray(W, np.float64)
+    out = np.empty(6, np.float64)
+    rc = lib.pvnet_pnp_refine(_dptr(p2), _dptr(p3), None if Wc is None else _dptr(Wc), _dptr(Kc), _dptr(x0),
+                              _dptr(out), p2.shape[0], 200, None)
+    if rc < 0:
+        raise RuntimeError("pvnet_pnp_refine: bad arguments")
+    return out
 
 LINEMOD_K = np.array([[572.4114, 0., 325.2611], [0., 573.57043, 242.04899], [0., 0., 1.]])  # base_utils.py:241-243
 
@@ -87,7 +140,7 @@ def _residuals(x, points_3d, points_2d, K, W=None):
     return d.ravel()
 
 
-def pnp(points_3d, points_2d, camera_matrix, method="iterative", init=None):
+def pnp(points_3d, points_2d, camera_matrix, method="iterative", init=None, backend="native"):
     """evaluation_utils.py:19-52  ->  [3,4] pose (R | t).  DLT initialisation + LM on the reprojection error."""
     points_3d = np.ascontiguousarray(points_3d, np.float64)
     points_2d = np.ascontiguousarray(points_2d, np.float64)
@@ -98,29 +151,28 @@ def pnp(points_3d, points_2d, camera_matrix, method="iterative", init=None):
         x0 = np.concatenate([rodrigues_inv(R0), t0])
     else:
         x0 = np.concatenate([rodrigues_inv(init[:, :3]), init[:, 3]])
-    sol = least_squares(_residuals, x0, args=(points_3d, points_2d, K), method="lm", xtol=1e-12, ftol=1e-12)
-    return np.concatenate([rodrigues(sol.x[:3]), sol.x[3:, None]], 1)
+    x = _refine(x0, points_3d, points_2d, K, None, backend)
+    return np.concatenate([rodrigues(x[:3]), x[3:, None]], 1)
 
 
-def uncertainty_pnp(points_2d, weights_2d, points_3d, camera_matrix):
+def uncertainty_pnp(points_2d, weights_2d, points_3d, camera_matrix, backend="native"):
     """extend_utils.py:63-114: weights_2d [pn,3] = (wxx, wxy, wyy); initialised from the 4 best-weighted points
     (P3P there; the same 4-point LM fit here), refined by LM on the weighted residuals (uncertainty_pnp.cpp:61-92)."""
     points_2d = np.asarray(points_2d, np.float64)
     points_3d = np.asarray(points_3d, np.float64)
     W = np.asarray(weights_2d, np.float64)
-    pose0 = pnp(points_3d, points_2d, camera_matrix)  # robust start (the reference's P3P start needs >= 4 good points)
+    pose0 = pnp(points_3d, points_2d, camera_matrix, backend=backend)  # robust start (the reference's P3P start needs >= 4 good points)
     x0 = np.concatenate([rodrigues_inv(pose0[:, :3]), pose0[:, 3]])
-    sol = least_squares(_residuals, x0, args=(points_3d, points_2d, np.asarray(camera_matrix, np.float64), W),
-                        method="lm", xtol=1e-12, ftol=1e-12)
-    return np.concatenate([rodrigues(sol.x[:3]), sol.x[3:, None]], 1)
+    x = _refine(x0, points_3d, points_2d, np.asarray(camera_matrix, np.float64), W, backend)
+    return np.concatenate([rodrigues(x[:3]), x[3:, None]], 1)
 
 
-def uncertainty_pnp_v2(points_2d, covars, points_3d, camera_matrix):
+def uncertainty_pnp_v2(points_2d, covars, points_3d, camera_matrix, backend="native"):
     """extend_utils.py:116-165: isotropic weight 1/lambda_max(cov) per key-point (0 when cov[0,0] < 1e-5)."""
     covars = np.asarray(covars, np.float64)
     w = np.array([0.0 if c[0, 0] < 1e-5 else 1.0 / np.max(np.linalg.eigvalsh(c)) for c in covars])
     W = np.stack([w, np.zeros_like(w), w], 1)
-    return uncertainty_pnp(points_2d, W, points_3d, camera_matrix)
+    return uncertainty_pnp(points_2d, W, points_3d, camera_matrix, backend=backend)
 
 
 # ---- metrics of Evaluator (evaluation_utils.py:75-134) -----------------------------------------------------

@@ -30,6 +30,19 @@ def test_exports_every_declared_symbol(lib):
     assert b"gfx950" in lib.pvnet_vote_build_info()
 
 
+def test_host_pnp_library_exports_every_declared_symbol():
+    """include/pvnet_pnp.h: the host-side pose refinement, incl. the reference's own `uncertainty_pnp` symbol"""
+    from pvnet_amd import pnp
+    build.build()
+    plib = pnp.load_pnp_library()
+    hdr = open(os.path.join(ROOT, "include", "pvnet_pnp.h")).read()
+    body = hdr[hdr.index('extern "C"'):]
+    names = set(re.findall(r"^(?:void|int)\s+([a-z0-9_]+)\s*\(", body, flags=re.M))
+    assert {"uncertainty_pnp", "pvnet_pnp_refine", "pvnet_angle_axis_to_matrix", "pvnet_matrix_to_angle_axis"} == names
+    for n in names:
+        assert hasattr(plib, n), f"{n} declared in include/pvnet_pnp.h but not exported"
+
+
 def test_library_contains_gfx950_code_object():
     blob = open(voting.LIB_PATH, "rb").read()
     assert b"gfx950" in blob and b"score_kernel" in blob and b"score_mfma_kernel" in blob

@@ -36,3 +36,83 @@ def test_pnp_with_noise_and_uncertainty(demo_fixture):
     e_plain = P.projection_2d_error(plain, target, f["bb8_3d"], f["K"])
     e_w = P.projection_2d_error(weighted, target, f["bb8_3d"], f["K"])
     assert e_plain < 5.0 and e_w < e_plain  # down-weighting the bad point helps (the paper's uncertainty-driven PnP)
+
+
+# ---- the native LM (libpvnet_pnp.so, include/pvnet_pnp.h) against scipy's MINPACK LM on the same problems ------------
+def _random_problem(rng, pn=9, noise=0.5):
+    r = rng.normal(size=3)
+    r *= rng.uniform(0.1, 2.5) / np.linalg.norm(r)
+    t = np.array([rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2), rng.uniform(0.6, 1.5)])
+    X = rng.uniform(-0.08, 0.08, size=(pn, 3))
+    pose = np.concatenate([P.rodrigues(r), t[:, None]], 1)
+    x = P.project(X, pose, P.LINEMOD_K) + rng.normal(size=(pn, 2)) * noise
+    return X, x, pose
+
+
+def test_native_lm_matches_scipy_lm():
+    rng = np.random.default_rng(5)
+    for _ in range(25):
+        X, x, _ = _random_problem(rng)
+        a = P.pnp(X, x, P.LINEMOD_K, backend="native")
+        b = P.pnp(X, x, P.LINEMOD_K, backend="scipy")
+        np.testing.assert_allclose(a, b, atol=2e-7)
+        s = rng.uniform(0.2, 3.0, size=9)
+        th = rng.uniform(0, np.pi, size=9)
+        cov = np.stack([np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]]) @ np.diag([q * q, 4 * q * q]) @
+                        np.array([[np.cos(t), np.sin(t)], [-np.sin(t), np.cos(t)]]) for q, t in zip(s, th)])
+        W = np.stack([np.linalg.inv(c) for c in cov])  # full symmetric 2x2 weights (wxx, wxy, wyy)
+        W3 = np.stack([W[:, 0, 0], W[:, 0, 1], W[:, 1, 1]], 1)
+        a = P.uncertainty_pnp(x, W3, X, P.LINEMOD_K, backend="native")
+        b = P.uncertainty_pnp(x, W3, X, P.LINEMOD_K, backend="scipy")
+        np.testing.assert_allclose(a, b, atol=2e-6)
+
+
+def test_reference_c_signature_uncertainty_pnp(demo_fixture):
+    """the symbol the reference's cffi stub binds (uncertainty_pnp.cpp:61-69): void, 6 double* + int"""
+    import ctypes as C
+    lib = P.load_pnp_library()
+    f = demo_fixture
+    p2 = np.ascontiguousarray(f["points_2d"], np.float64)
+    p3 = np.ascontiguousarray(f["points_3d"], np.float64)
+    w = np.ascontiguousarray(np.tile([1.0, 0.0, 1.0], (9, 1)))
+    K = np.ascontiguousarray(f["K"], np.float64)
+    target = f["pose"].astype(np.float64)
+    init = np.concatenate([P.rodrigues_inv(target[:, :3]) + 0.05, target[:, 3] + 0.02])  # a perturbed start
+    out = np.zeros(6)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    lib.uncertainty_pnp(dp(p2), dp(p3), dp(w), dp(K), dp(init), dp(out), 9)
+    np.testing.assert_allclose(P.rodrigues(out[:3]), target[:, :3], atol=1e-5)
+    np.testing.assert_allclose(out[3:], target[:, 3], atol=1e-6)
+
+
+def test_native_angle_axis_maps():
+    import ctypes as C
+    lib = P.load_pnp_library()
+    rng = np.random.default_rng(2)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    for th in [0.0, 1e-9, 1e-4, 0.3, 1.7, 3.0, np.pi - 1e-7]:
+        k = rng.normal(size=3)
+        aa = np.ascontiguousarray(k / np.linalg.norm(k) * th)
+        R = np.zeros(9)
+        lib.pvnet_angle_axis_to_matrix(dp(aa), dp(R))
+        np.testing.assert_allclose(R.reshape(3, 3), P.rodrigues(aa), atol=1e-12)
+        back = np.zeros(3)
+        lib.pvnet_matrix_to_angle_axis(dp(R), dp(back))
+        R2 = np.zeros(9)
+        lib.pvnet_angle_axis_to_matrix(dp(back), dp(R2))
+        np.testing.assert_allclose(R2, R, atol=1e-9)
+
+
+def test_native_lm_rejects_bad_arguments_and_survives_degenerate_input():
+    import ctypes as C
+    lib = P.load_pnp_library()
+    z = np.zeros(27)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    out = np.zeros(6)
+    assert lib.pvnet_pnp_refine(dp(z), dp(z), None, dp(z), dp(z), dp(out), 2, 10, None) == -1  # pn < 3
+    assert lib.pvnet_pnp_refine(None, dp(z), None, dp(z), dp(z), dp(out), 9, 10, None) == -1
+    # all points at the camera centre: evaluation fails, the start pose comes back untouched
+    init = np.array([0.1, 0.2, 0.3, 0.0, 0.0, 0.0])
+    assert lib.pvnet_pnp_refine(dp(z), dp(z), None, dp(np.ascontiguousarray(P.LINEMOD_K.ravel())), dp(init), dp(out), 9,
+                                10, None) == 0
+    np.testing.assert_array_equal(out, init)
