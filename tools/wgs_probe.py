@@ -1,4 +1,5 @@
-"""Development aid: multi-stream throughput of the whole path against the scoring grid size (PVNET_SCORE_WGS_PER_CU).
+"""Development aid: multi-stream throughput of the whole path against one launch-time knob (default: the scoring grid
+size PVNET_SCORE_WGS_PER_CU; KNOB=<env var> WGS_LIST=<comma list> select another).
     python tools/wgs_probe.py [streams] [steps]"""
 import os
 import sys
@@ -30,9 +31,10 @@ def run(n):
 run(400)
 for rnd in range(2):
     for wgs in (os.environ.get("WGS_LIST", "3,4,6,8,12,0")).split(","):
-        os.environ["PVNET_SCORE_WGS_PER_CU"] = wgs
+        os.environ[os.environ.get("KNOB", "PVNET_SCORE_WGS_PER_CU")] = wgs
         run(100)
         t0 = time.perf_counter()
         run(K)
         dt = (time.perf_counter() - t0) / K
-        print(f"{S} streams, PVNET_SCORE_WGS_PER_CU={wgs:>2s}: {dt * 1e3:.4f} ms per batch of 32", flush=True)
+        print(f"{S} streams, {os.environ.get('KNOB', 'PVNET_SCORE_WGS_PER_CU')}={wgs:>2s}: {dt * 1e3:.4f} ms per batch of 32",
+              flush=True)
