@@ -524,3 +524,28 @@ def test_concurrent_streams_reproduce_serial_results():
         torch.cuda.synchronize()
         for a, b in zip(serial, outs):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("knobs", [
+    {"PVNET_K1_BLOCKS_PER_IMAGE": "4"},                       # persistent mask-kernel grid
+    {"PVNET_SCORE_WGS_PER_CU": "0"}, {"PVNET_SCORE_WGS_PER_CU": "2"},  # one workgroup per item / a small persistent grid
+    {"PVNET_SCORE_CHUNK": "64"}, {"PVNET_SCORE_CHUNK": "256"},  # pixels per count row (2 and 8..16 tiles per item)
+    {"PVNET_SCORE_HPL": "2"}, {"PVNET_SCORE_HPL": "4"},        # fewer hypotheses per work item (MH = 2, 4)
+    {"PVNET_COMPACT_KG": "1"}, {"PVNET_COMPACT_KG": "9"},
+])
+def test_launch_knobs_do_not_change_results(knobs, monkeypatch):
+    """Tuning knobs re-shape grids and work items, never results: literal mode stays bit-equal to
+    the default configuration (counts included), fast mode keeps its winners and key-points."""
+    mask, planar, _, _ = small_batch(b=3, first=1300, h=200, w=280, radius=31)
+    m, v = to_dev(mask, planar)
+    ref_l, dbg_l = voting.ransac_voting_layer_v3(m, v, 700, inlier_thresh=0.99, seed=9, literal=True, return_debug=True)
+    ref_f, dbg_f = voting.ransac_voting_layer_v3(m, v, 700, inlier_thresh=0.99, seed=9, return_debug=True)
+    counts_l, counts_f = dbg_l["counts"].clone(), dbg_f["counts"].clone()
+    ref_l, ref_f = ref_l.clone(), ref_f.clone()
+    for k, x in knobs.items():
+        monkeypatch.setenv(k, x)
+    out_l, d_l = voting.ransac_voting_layer_v3(m, v, 700, inlier_thresh=0.99, seed=9, literal=True, return_debug=True)
+    out_f, d_f = voting.ransac_voting_layer_v3(m, v, 700, inlier_thresh=0.99, seed=9, return_debug=True)
+    assert torch.equal(d_l["counts"], counts_l) and torch.equal(out_l, ref_l)
+    assert torch.equal(d_f["counts"], counts_f) and torch.equal(out_f, ref_f)
+

@@ -108,3 +108,11 @@ def test_reference_import_path_resolves_to_hip_layer():
     for n in ("generate_hypothesis", "voting_for_hypothesis", "generate_hypothesis_vanishing_point",
               "voting_for_hypothesis_vanishing_point"):  # ransac_voting.cpp:102-107
         assert callable(getattr(ops, n))
+
+
+def test_oversized_matrix_pipe_items_are_refused(monkeypatch):
+    """the wrapped vote accumulators of the matrix-pipe kernel hold < 512 votes: a work item of >= 1024 pixels is
+    refused by pvnet_vote_layout instead of miscounting"""
+    monkeypatch.setenv("PVNET_SCORE_CHUNK", "256")
+    with pytest.raises(RuntimeError, match="PVNET_E_UNSUPPORTED"):
+        voting.vote_layout(2, 120, 160, 9, 100, 30000)  # 100 hypotheses: 4 chunks per work item
