@@ -23,8 +23,10 @@
 //   K4 score          DOMINANT.  Fast mode (score_mfma_kernel): the vote is two 3-term fp32 dot products and a
 //                     compare; every operand is split into three bf16 parts, so each dot product is ONE
 //                     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (fp32-equivalent accuracy, measured), and
-//                     the lane that owns the hypothesis counts its 16 results with cnt += clamp(dt - |cr|)
-//                     (the 2^90 record scaling makes the clamp an exact 0/1): 2 MFMAs + 2 VALU ops per test.  Records are expanded and staged in LDS once per work item.
+//                     the lane that owns the hypothesis counts its 16 results as t = clamp(dt - |cr|) (the 2^90
+//                     record scaling makes the clamp an exact 1.0f / 0) summed two at a time by a wrapping
+//                     v_add3_u32: 2 MFMAs + 1.5 VALU ops per test (vote8).  Records are expanded and staged in
+//                     LDS once per work item.
 //                     Literal mode (score_kernel<HPL,true>): "lane owns hypotheses" on the VALU in the
 //                     reference's float32 operation order, bit-exact with the reference's kernels.
 //                     Work items are strided over a persistent grid; counts go out as uint16 rows.
