@@ -154,6 +154,15 @@ int pvnet_vote_confidence(const float* kpts, float thresh, float* out_conf, uint
 int pvnet_vote_distribution(const float* mean, float* out_cov, int b, int h, int w, int vn, int hn, int max_num,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* ransac_motion_voting (ransac_voting_gpu.py:960-981): out_pts[b,vn,2] = mean over the image's foreground pixels of
+ * (vertex + (x, y)); zeros for an image without foreground.  mask / vertex as for pvnet_vote_v3 (any strides, read in
+ * place, only foreground vectors are touched).  Needs its own small workspace (bit mask + per-segment float64 sums):
+ * pvnet_motion_workspace_bytes(b, h, w, vn) bytes, 256-byte aligned. */
+size_t pvnet_motion_workspace_bytes(int b, int h, int w, int vn);
+int pvnet_motion_voting(const void* mask, int mask_dtype, const int64_t mask_strides[3], const float* vertex,
+                        const int64_t vertex_strides[5], int b, int h, int w, int vn, float* out_pts, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 /* Op-level entry points with the reference extension's tensor layouts.
  * direct [tn,vn,2] f32, coords [tn,2] f32, idxs [hn,vn,2] i32 -> hypo_pts [hn,vn,2] f32 (fully written; degenerate
  * pairs give (0,0) as the reference's at::zeros + early return do, ransac_voting_kernel.cu:42-43,75). */

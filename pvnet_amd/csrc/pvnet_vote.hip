@@ -1024,6 +1024,69 @@ __global__ __launch_bounds__(256) void distribution_kernel(VoteParams P, const f
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// ransac_motion_voting (ransac_voting_gpu.py:960-981): per image and key-point, the mean over the foreground pixels
+// of (vertex + pixel coordinate).  Reads the field only where the bit mask of K1 is set: one block per 4096-pixel
+// segment sums its pixels in float64 (lane = pixel of a 64-pixel word, so a wave reads 256 contiguous bytes per plane
+// of the planar field), one block per (image, key-point) adds the segment sums in order and divides.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void motion_partial_kernel(VoteParams P, double* __restrict__ part) {
+    const int sgi = blockIdx.x, bi = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (P.seg0[bi * P.nseg + sgi] == 0) return;  // block-uniform; the final kernel skips this segment's slots too
+    constexpr int WPW = SEG_WORDS / 4;  // words per wave
+    unsigned long long my = 0;  // bit i: this lane's pixel of the wave's word i is foreground
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+        const int wd = (sgi * 4 + wave) * WPW + i;
+        const unsigned long long bits = wd < P.words ? P.bits[(size_t)bi * P.words + wd] : 0ull;
+        my |= ((bits >> lane) & 1ull) << i;
+    }
+    __shared__ double s_part[4][2];
+    for (int k = 0; k < P.vn; ++k) {
+        double sx = 0.0, sy = 0.0;
+#pragma unroll 4
+        for (int i = 0; i < WPW; ++i) {
+            if (!((my >> i) & 1ull)) continue;
+            const int p = ((sgi * 4 + wave) * WPW + i) * 64 + lane;
+            const int y = p / P.w, x = p - y * P.w;
+            const float* v = P.vertex + (int64_t)bi * P.vs0 + (int64_t)y * P.vs1 + (int64_t)x * P.vs2 + (int64_t)k * P.vs3;
+            sx += (double)(v[0] + (float)x);      // the reference adds in float32 (:975), then averages
+            sy += (double)(v[P.vs4] + (float)y);
+        }
+        sx = wave_reduce_add(sx);
+        sy = wave_reduce_add(sy);
+        if (lane == 0) { s_part[wave][0] = sx; s_part[wave][1] = sy; }
+        __syncthreads();
+        if (threadIdx.x < 2)
+            part[(((size_t)bi * P.nseg + sgi) * P.vn + k) * 2 + threadIdx.x] =
+                (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void motion_final_kernel(VoteParams P, const double* __restrict__ part,
+                                                          float* __restrict__ out) {
+    const int k = blockIdx.x, bi = blockIdx.y, lane = threadIdx.x;
+    double sx = 0.0, sy = 0.0;
+    int n = 0;
+    for (int sgi = lane; sgi < P.nseg; sgi += 64) {
+        const int c = P.seg0[bi * P.nseg + sgi];
+        if (c == 0) continue;
+        n += c;
+        sx += part[(((size_t)bi * P.nseg + sgi) * P.vn + k) * 2];
+        sy += part[(((size_t)bi * P.nseg + sgi) * P.vn + k) * 2 + 1];
+    }
+    sx = wave_reduce_add(sx);
+    sy = wave_reduce_add(sy);
+    n = wave_reduce_add(n);
+    if (lane == 0) {  // an image without foreground returns zeros (:969-971)
+        out[((size_t)bi * P.vn + k) * 2] = n ? (float)(sx / n) : 0.f;
+        out[((size_t)bi * P.vn + k) * 2 + 1] = n ? (float)(sy / n) : 0.f;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
 // op-level kernels with the reference extension's layouts
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void op_generate_hypothesis_kernel(const float* __restrict__ direct,
@@ -1109,6 +1172,21 @@ int launch_score(const VoteParams& P, dim3 grid, hipStream_t s) {
     return 0;
 }
 
+int launch_mask_bits(const VoteParams& P, hipStream_t s) {
+    const int k1g = env_int("PVNET_K1_BLOCKS_PER_IMAGE", 0);  // > 0: persistent grid, blocks walk the segments
+    dim3 grid(k1g > 0 && k1g < P.nseg ? k1g : P.nseg, P.b);
+    switch (P.mask_dtype) {
+        case PVNET_MASK_U8: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_U8>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
+        case PVNET_MASK_I16: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I16>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
+        case PVNET_MASK_I32: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I32>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
+        case PVNET_MASK_I64: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I64>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
+        case PVNET_MASK_F32: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_F32>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
+        case PVNET_MASK_LOGITS_F32: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_LOGITS_F32>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
+        default: return PVNET_E_BADARG;
+    }
+    return 0;
+}
+
 int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
     const bool literal = (P.flags & PVNET_F_LITERAL) != 0;
     auto mark = [&](int i) -> hipError_t { return ev ? hipEventRecord(ev[i], s) : hipSuccess; };
@@ -1117,17 +1195,9 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
     const int stages = env_int("PVNET_DEV_STAGES", 0x3F);
     PV_HIP(mark(0));
     {   // K1
-        const int k1g = env_int("PVNET_K1_BLOCKS_PER_IMAGE", 0);  // > 0: persistent grid, blocks walk the segments
-        dim3 grid(k1g > 0 && k1g < P.nseg ? k1g : P.nseg, P.b);
-        switch ((stages & 1) ? P.mask_dtype : -1) {
-            case -1: break;
-            case PVNET_MASK_U8: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_U8>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
-            case PVNET_MASK_I16: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I16>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
-            case PVNET_MASK_I32: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I32>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
-            case PVNET_MASK_I64: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I64>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
-            case PVNET_MASK_F32: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_F32>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
-            case PVNET_MASK_LOGITS_F32: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_LOGITS_F32>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
-            default: return PVNET_E_BADARG;
+        if (stages & 1) {
+            int rc = launch_mask_bits(P, s);
+            if (rc) return rc;
         }
         PV_LAUNCH_CHECK();
         PV_HIP(mark(1));
@@ -1401,6 +1471,61 @@ int pvnet_vote_distribution(const float* mean, float* out_cov, int b, int h, int
     if (rc) return rc;
     hipLaunchKernelGGL(distribution_kernel, dim3(vn, b), dim3(256), 0, static_cast<hipStream_t>(stream), P, mean,
                        out_cov);
+    PV_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- ransac_motion_voting: its own small workspace (bit mask, segment counts, per-segment float64 sums) ----------
+static int motion_layout(int b, int h, int w, int vn, size_t off[4], int* words, int* nseg) {
+    if (b <= 0 || h <= 0 || w <= 0 || vn <= 0) return PVNET_E_BADARG;
+    if ((long long)h * w > (1ll << 30) || b > 65535 || vn > 65535) return PVNET_E_UNSUPPORTED;
+    *words = (int)(((long long)h * w + 63) / 64);
+    *nseg = (*words + SEG_WORDS - 1) / SEG_WORDS;
+    off[0] = 0;                                                                    // bits  u64 [b][words]
+    off[1] = align_up(off[0] + sizeof(uint64_t) * (size_t)b * *words, 256);         // seg   i32 [2][b][nseg]
+    off[2] = align_up(off[1] + sizeof(int32_t) * 2 * (size_t)b * *nseg, 256);       // part  f64 [b][nseg][vn][2]
+    off[3] = align_up(off[2] + sizeof(double) * 2 * (size_t)b * *nseg * vn, 256);   // total
+    return 0;
+}
+
+size_t pvnet_motion_workspace_bytes(int b, int h, int w, int vn) {
+    size_t off[4];
+    int words, nseg;
+    return motion_layout(b, h, w, vn, off, &words, &nseg) == 0 ? off[3] : 0;
+}
+
+int pvnet_motion_voting(const void* mask, int mask_dtype, const int64_t mask_strides[3], const float* vertex,
+                        const int64_t vertex_strides[5], int b, int h, int w, int vn, float* out_pts, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+    if (!mask || !mask_strides || !vertex || !vertex_strides || !out_pts || !workspace) return PVNET_E_BADARG;
+    if (mask_dtype < PVNET_MASK_U8 || mask_dtype > PVNET_MASK_F32) return PVNET_E_BADARG;
+    size_t off[4];
+    int words, nseg;
+    int rc = motion_layout(b, h, w, vn, off, &words, &nseg);
+    if (rc) return rc;
+    if (workspace_bytes < off[3]) return PVNET_E_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0) return PVNET_E_BADARG;
+    char* base = static_cast<char*>(workspace);
+    VoteParams P = {};
+    P.mask = mask; P.ms0 = mask_strides[0]; P.ms1 = mask_strides[1]; P.ms2 = mask_strides[2];
+    P.num_classes = 1;
+    P.mask_dtype = mask_dtype;
+    P.mask_linear = (mask_strides[2] == 1 && mask_strides[1] == w) ? 1 : 0;
+    P.vertex = vertex;
+    P.vs0 = vertex_strides[0]; P.vs1 = vertex_strides[1]; P.vs2 = vertex_strides[2]; P.vs3 = vertex_strides[3];
+    P.vs4 = vertex_strides[4];
+    P.b = b; P.h = h; P.w = w; P.vn = vn; P.npix = h * w; P.words = words; P.nseg = nseg;
+    P.bits = reinterpret_cast<uint64_t*>(base + off[0]);
+    P.seg = reinterpret_cast<int32_t*>(base + off[1]);
+    P.seg0 = P.seg + (size_t)b * nseg;
+    double* part = reinterpret_cast<double*>(base + off[2]);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = launch_mask_bits(P, s);
+    if (rc) return rc;
+    PV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(motion_partial_kernel, dim3(nseg, b), dim3(256), 0, s, P, part);
+    PV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(motion_final_kernel, dim3(vn, b), dim3(64), 0, s, P, part, out_pts);
     PV_LAUNCH_CHECK();
     return 0;
 }

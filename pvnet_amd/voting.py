@@ -74,6 +74,11 @@ def load_library() -> C.CDLL:
     lib.pvnet_voting_for_hypothesis.argtypes = [f32p, f32p, f32p, u8p, C.c_int, C.c_int, C.c_int, C.c_float,
                                                 C.c_void_p]
     ws_tail = [C.c_int] * 6 + [C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.pvnet_motion_workspace_bytes.restype = C.c_size_t
+    lib.pvnet_motion_workspace_bytes.argtypes = [C.c_int] * 4
+    lib.pvnet_motion_voting.restype = C.c_int
+    lib.pvnet_motion_voting.argtypes = [C.c_void_p, C.c_int, i64p, f32p, i64p, C.c_int, C.c_int, C.c_int, C.c_int, f32p,
+                                        C.c_void_p, C.c_size_t, C.c_void_p]
     lib.pvnet_vote_confidence.restype = C.c_int
     lib.pvnet_vote_confidence.argtypes = [f32p, C.c_float, f32p, C.c_uint32] + ws_tail
     lib.pvnet_vote_distribution.restype = C.c_int
@@ -335,17 +340,21 @@ def generate_hypothesis_counts(mask, vertex, round_hyp_num, inlier_thresh=0.999,
 
 
 def ransac_motion_voting(mask, vertex):
-    """ransac_voting_gpu.py:960-981: per image, the mean over foreground pixels of (vertex + pixel coordinate).
-    Off the hot path and device-agnostic upstream as well: plain torch, vectorised over the batch."""
-    b, h, w, vn, _ = vertex.shape
-    fg = (mask.to(torch.uint8) if mask.dtype != torch.bool else mask).ne(0)
-    ys, xs = torch.meshgrid(torch.arange(h, device=vertex.device, dtype=torch.float32),
-                            torch.arange(w, device=vertex.device, dtype=torch.float32), indexing="ij")
-    coords = torch.stack([xs, ys], -1)[None, :, :, None, :]  # (x, y) = (col, row)
-    wgt = fg[..., None, None].to(torch.float32)
-    cnt = wgt.sum(dim=(1, 2)).clamp_min(1.0)
-    out = ((vertex.float() + coords) * wgt).sum(dim=(1, 2)) / cnt
-    return torch.where(fg.flatten(1).any(1)[:, None, None], out, torch.zeros_like(out))
+    """Drop-in for ransac_voting_gpu.py:960-981: per image, the mean over foreground pixels of (vertex + pixel
+    coordinate); zeros for an image without foreground.  HIP: the mask kernel's bit mask, then only the foreground
+    vectors of the (strided) field are read and summed in float64 (``pvnet_motion_voting``)."""
+    lib = load_library()
+    mask, vertex, b, h, w, vn, _, _, _ = _prepare(mask, vertex, 1, 0, None)
+    dev = vertex.device
+    with torch.cuda.device(dev):
+        nbytes = lib.pvnet_motion_workspace_bytes(b, h, w, vn)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        out = torch.empty((b, vn, 2), dtype=torch.float32, device=dev)
+        _check(lib.pvnet_motion_voting(C.c_void_p(mask.data_ptr()), _MASK_CODES[mask.dtype], _strides(mask, 3),
+                                       C.c_void_p(vertex.data_ptr()), _strides(vertex, 5), b, h, w, vn,
+                                       C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), C.c_size_t(nbytes),
+                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "pvnet_motion_voting")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -350,6 +350,33 @@ def test_motion_voting_matches_oracle():
     np.testing.assert_allclose(out, O.ransac_motion_voting(mask, vnp), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("h,w,vn,dt", [(480, 640, 9, torch.int64), (37, 53, 1, torch.uint8), (130, 77, 4, torch.float32)])
+def test_motion_voting_shapes_dtypes_and_empty_images(h, w, vn, dt):
+    """pvnet_motion_voting against the reference's formula (:960-981) in float64 on the same inputs; arbitrary (non
+    unit) vectors, strided field view, an empty image, a single-pixel image, a full-frame image"""
+    rng = np.random.default_rng(h * 1000 + w)
+    b = 5
+    mask = (rng.random((b, h, w)) < 0.03).astype(np.int64)
+    mask[1] = 0
+    mask[2] = 0
+    mask[2, h // 2, w // 3] = 3  # .byte() != 0
+    mask[3] = 1
+    planar = (rng.normal(size=(b, 2 * vn, h, w)) * 7.0).astype(np.float32)
+    m = torch.from_numpy(mask).to(dev()).to(dt)
+    v = synth.planar_to_vertex_view(torch.from_numpy(planar).to(dev()))
+    out = voting.ransac_motion_voting(m, v).cpu().numpy()
+    vnp = synth.planar_to_vertex_view(planar).astype(np.float64)
+    ys, xs = np.mgrid[0:h, 0:w]
+    want = np.zeros((b, vn, 2))
+    for bi in range(b):
+        fg = mask[bi] != 0
+        if fg.any():
+            want[bi, :, 0] = (vnp[bi][fg][:, :, 0] + xs[fg][:, None]).mean(0)
+            want[bi, :, 1] = (vnp[bi][fg][:, :, 1] + ys[fg][:, None]).mean(0)
+    assert (out[1] == 0).all()
+    np.testing.assert_allclose(out, want, rtol=1e-5, atol=1e-3)
+
+
 def test_demo_fixture_end_to_end_pose(demo_fixture):
     """BASELINE.json config 2 without the (absent) backbone weights: ground-truth field of the demo image ->
     HIP voting -> host PnP -> the fixture's pose (tools/demo.py:166-179)."""

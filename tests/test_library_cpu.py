@@ -110,6 +110,15 @@ def test_reference_import_path_resolves_to_hip_layer():
         assert callable(getattr(ops, n))
 
 
+def test_motion_voting_workspace_and_argument_checks(lib):
+    lib.pvnet_motion_workspace_bytes.restype = C.c_size_t
+    n = lib.pvnet_motion_workspace_bytes(32, 480, 640, 9)
+    assert 32 * 4800 * 8 < n < 8 * 1024 * 1024 and n % 256 == 0  # bit mask + segment counts + per-segment sums
+    assert lib.pvnet_motion_workspace_bytes(0, 480, 640, 9) == 0
+    z3, z5 = (C.c_int64 * 3)(), (C.c_int64 * 5)()
+    assert lib.pvnet_motion_voting(None, 3, z3, None, z5, 1, 4, 4, 1, None, None, 0, None) == -1  # PVNET_E_BADARG
+
+
 def test_oversized_matrix_pipe_items_are_refused(monkeypatch):
     """the wrapped vote accumulators of the matrix-pipe kernel hold < 512 votes: a work item of >= 1024 pixels is
     refused by pvnet_vote_layout instead of miscounting"""

@@ -43,3 +43,54 @@ run("batch 128", 128, 40, 1024, 0.99, steps=10)
 run("literal mode (reference fp32 order)", 32, 40, 1024, 0.99, literal=True, steps=5)
 run("hn=4096 (distribution estimate), b=8", 8, 40, 4096, 0.99, steps=10)
 run("hn=256, b=32", 32, 40, 256, 0.99)
+
+
+# ---- the sibling entry points of SURVEY.md 8(f), timed the same way ------------------------------------------------
+def timeit(name, fn, b, steps=50):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print(f"{name:72s} b={b:3d}: {dt * 1e6:8.1f} us/call  {b / dt:10.0f} images/s", flush=True)
+
+
+B = 32
+mask, planar, _ = synth.make_batch(B, radius=40, noise=True, background="normal")
+m = torch.from_numpy(mask).to(dev)
+pl = torch.from_numpy(planar).to(dev)
+v = synth.planar_to_vertex_view(pl)
+seg = torch.stack([1.0 - m.float(), m.float()], 1).contiguous() + 0.1 * torch.randn(B, 2, 480, 640, device=dev)
+timeit("argmax(seg_pred) + ransac_voting_layer_v3 (tools/demo.py:52-55)",
+       lambda: voting.ransac_voting_layer_v3(torch.argmax(seg, 1), v, 1024, inlier_thresh=0.99, seed=1), B)
+timeit("fused: ransac_voting_layer_v3_from_logits (f#2)",
+       lambda: voting.ransac_voting_layer_v3_from_logits(seg, v, 1024, inlier_thresh=0.99, seed=1), B)
+timeit("ransac_voting_layer_v5: v3 + confidence at 0.999 (f#3), max_num=30000",
+       lambda: voting.ransac_voting_layer_v5(m, v, 1024, inlier_thresh=0.99, max_num=30000, seed=1), B)
+kp = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=1)
+timeit("estimate_voting_distribution_with_mean: 4096 hypotheses + covariance (f#3)",
+       lambda: voting.estimate_voting_distribution_with_mean(m, v, kp, seed=1), B, steps=20)
+timeit("generate_hypothesis (py-level): all hypotheses + counts, 1024 (f#4)",
+       lambda: voting.generate_hypothesis_counts(m, v, 1024, inlier_thresh=0.99, seed=1), B)
+timeit("ransac_motion_voting (f#4)", lambda: voting.ransac_motion_voting(m, v), B)
+kp_np, cov = kp[0].cpu().numpy().astype(np.float64), None
+from pvnet_amd import pnp  # noqa: E402
+X = np.random.default_rng(0).uniform(-0.08, 0.08, size=(9, 3))
+pose = np.concatenate([pnp.rodrigues(np.array([0.3, -0.2, 0.1])), np.array([[0.02], [-0.03], [0.9]])], 1)
+x2 = pnp.project(X, pose, pnp.LINEMOD_K) + np.random.default_rng(1).normal(size=(9, 2)) * 0.3
+for backend in ("native", "scipy"):
+    t0 = time.perf_counter()
+    for _ in range(200):
+        pnp.pnp(X, x2, pnp.LINEMOD_K, backend=backend)
+    print(f"host pnp (DLT + LM, 9 points), backend={backend:7s}: {(time.perf_counter() - t0) / 200 * 1e6:8.1f} us/call",
+          flush=True)
+W = np.tile([1.0, 0.0, 1.0], (9, 1))
+for backend in ("native", "scipy"):
+    t0 = time.perf_counter()
+    for _ in range(200):
+        pnp.uncertainty_pnp(x2, W, X, pnp.LINEMOD_K, backend=backend)
+    print(f"host uncertainty_pnp (f#3), backend={backend:7s}: {(time.perf_counter() - t0) / 200 * 1e6:8.1f} us/call",
+          flush=True)
