@@ -32,6 +32,17 @@ void uncertainty_pnp(double* pts2d, double* pts3d, double* wgt2d, double* K, dou
 int pvnet_pnp_refine(const double* pts2d, const double* pts3d, const double* wgt2d, const double* K,
                      const double* init_rt, double* result_rt, int pn, int max_iterations, double* final_cost);
 
+/* The whole of `pnp` (lib/utils/evaluation_utils.py:19-52) / `uncertainty_pnp` (extend_utils.py:63-114) for one image:
+ * linear start (DLT on normalised image points, projected onto SO(3); pn >= 6) + LM on the reprojection error, then --
+ * if wgt2d is given -- LM on the 2x2-weighted residuals from there.  result_rt [6] = angle-axis + translation.
+ * Returns the LM iterations taken (>= 0), -1 on bad arguments, -2 if the linear start is degenerate. */
+int pvnet_pnp_solve(const double* pts2d, const double* pts3d, const double* wgt2d, const double* K, double* result_rt,
+                    int pn);
+/* n images that share the object points: pts2d [n,pn,2], wgt2d [n,pn,3] or NULL, result_rt [n,6] (zeros where the
+ * solve failed).  Returns the number of failed images, -1 on bad arguments. */
+int pvnet_pnp_solve_batch(const double* pts2d, const double* pts3d, const double* wgt2d, const double* K,
+                          double* result_rt, int n, int pn);
+
 /* angle-axis <-> rotation matrix (cv2.Rodrigues / ceres::AngleAxisToRotationMatrix), row-major R[9] */
 void pvnet_angle_axis_to_matrix(const double* aa, double* R);
 void pvnet_matrix_to_angle_axis(const double* R, double* aa);

@@ -120,6 +120,120 @@ bool solve6(const double* A, const double* b, double* x) {
 
 constexpr int MAX_PN = 4096;
 
+// eigen-decomposition of a symmetric n x n matrix (row-major, n <= 12) by cyclic Jacobi rotations:
+// A -> diagonal (eigenvalues in w), V columns = eigenvectors
+void jacobi_eigen(double* A, int n, double* V, double* w) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * n + j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) (i == j ? diag : off) += A[i * n + j] * A[i * n + j];
+        if (off <= 1e-30 * diag || off == 0.0) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < n; ++k) {  // A <- J^T A J, applied as column then row rotations
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - sn * akq;
+                    A[k * n + q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - sn * aqk;
+                    A[q * n + k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - sn * vkq;
+                    V[k * n + q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
+}
+
+double det3(const double* M) {
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+bool inverse3(const double* M, double* I) {
+    const double d = det3(M);
+    if (!(std::fabs(d) > 1e-300)) return false;
+    I[0] = (M[4] * M[8] - M[5] * M[7]) / d; I[1] = (M[2] * M[7] - M[1] * M[8]) / d; I[2] = (M[1] * M[5] - M[2] * M[4]) / d;
+    I[3] = (M[5] * M[6] - M[3] * M[8]) / d; I[4] = (M[0] * M[8] - M[2] * M[6]) / d; I[5] = (M[2] * M[3] - M[0] * M[5]) / d;
+    I[6] = (M[3] * M[7] - M[4] * M[6]) / d; I[7] = (M[1] * M[6] - M[0] * M[7]) / d; I[8] = (M[0] * M[4] - M[1] * M[3]) / d;
+    return true;
+}
+
+// Linear start of the pose (what stands in for the first stage of cv2.solvePnP's ITERATIVE flag): DLT on normalised
+// image points with conditioned object points, the 3x3 block projected onto SO(3).  false on degenerate input.
+bool dlt_pose(const double* x2, const double* x3, const double* K, int pn, double* R, double* t) {
+    double Ki[9];
+    if (pn < 6 || !inverse3(K, Ki)) return false;
+    double c[3] = {0, 0, 0};
+    for (int i = 0; i < pn; ++i)
+        for (int a = 0; a < 3; ++a) c[a] += x3[3 * i + a] / pn;
+    double s = 0;
+    for (int i = 0; i < pn; ++i)
+        for (int a = 0; a < 3; ++a) s += (x3[3 * i + a] - c[a]) * (x3[3 * i + a] - c[a]);
+    s = std::sqrt(s / pn) + 1e-12;
+    double M[144];  // A^T A of the 2 pn x 12 DLT system
+    std::memset(M, 0, sizeof(M));
+    for (int i = 0; i < pn; ++i) {
+        const double u = x2[2 * i], v = x2[2 * i + 1];
+        const double zn = Ki[6] * u + Ki[7] * v + Ki[8];
+        const double xn = (Ki[0] * u + Ki[1] * v + Ki[2]) / zn, yn = (Ki[3] * u + Ki[4] * v + Ki[5]) / zn;
+        const double Xh[4] = {(x3[3 * i] - c[0]) / s, (x3[3 * i + 1] - c[1]) / s, (x3[3 * i + 2] - c[2]) / s, 1.0};
+        double r0[12], r1[12];
+        for (int a = 0; a < 4; ++a) {
+            r0[a] = Xh[a]; r0[4 + a] = 0; r0[8 + a] = -xn * Xh[a];
+            r1[a] = 0; r1[4 + a] = Xh[a]; r1[8 + a] = -yn * Xh[a];
+        }
+        for (int a = 0; a < 12; ++a)
+            for (int b = 0; b < 12; ++b) M[a * 12 + b] += r0[a] * r0[b] + r1[a] * r1[b];
+    }
+    double V[144], w[12];
+    jacobi_eigen(M, 12, V, w);
+    int kmin = 0;
+    for (int i = 1; i < 12; ++i)
+        if (w[i] < w[kmin]) kmin = i;
+    double P[12];
+    for (int i = 0; i < 12; ++i) P[i] = V[i * 12 + kmin];
+    double P3[9] = {P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]};
+    if (det3(P3) < 0) {
+        for (double& v : P) v = -v;
+        for (double& v : P3) v = -v;
+    }
+    // SVD of the 3x3 block through the eigen-decomposition of P3^T P3 = V S^2 V^T;  R = U V^T = P3 V S^-1 V^T
+    double G[9], W3[9], e[3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) G[a * 3 + b] = P3[a] * P3[b] + P3[3 + a] * P3[3 + b] + P3[6 + a] * P3[6 + b];
+    jacobi_eigen(G, 3, W3, e);
+    double sv[3], smean = 0;
+    for (int a = 0; a < 3; ++a) {
+        if (!(e[a] > 1e-300)) return false;
+        sv[a] = std::sqrt(e[a]);
+        smean += sv[a] / 3.0;
+    }
+    double T[9];  // V S^-1 V^T
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+            T[a * 3 + b] = W3[a * 3] * W3[b * 3] / sv[0] + W3[a * 3 + 1] * W3[b * 3 + 1] / sv[1] + W3[a * 3 + 2] * W3[b * 3 + 2] / sv[2];
+    matmul3(P3, T, R);
+    if (det3(R) < 0)
+        for (int a = 0; a < 9; ++a) R[a] = -R[a];
+    for (int a = 0; a < 3; ++a) {  // undo the conditioning X = (Xw - c) / s
+        const double tp = P[4 * a + 3] / smean - (R[a * 3] * c[0] + R[a * 3 + 1] * c[1] + R[a * 3 + 2] * c[2]) / s;
+        t[a] = tp * s;
+    }
+    return std::isfinite(t[0]) && std::isfinite(t[1]) && std::isfinite(t[2]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -206,6 +320,38 @@ void uncertainty_pnp(double* pts2d, double* pts3d, double* wgt2d, double* K, dou
                      int pn) {
     if (pvnet_pnp_refine(pts2d, pts3d, wgt2d, K, init_rt, result_rt, pn, 100, nullptr) < 0 && init_rt && result_rt)
         std::memcpy(result_rt, init_rt, 6 * sizeof(double));
+}
+
+int pvnet_pnp_solve(const double* pts2d, const double* pts3d, const double* wgt2d, const double* K, double* result_rt,
+                    int pn) {
+    if (!pts2d || !pts3d || !K || !result_rt || pn < 6 || pn > MAX_PN) return -1;
+    double R[9], t[3], x0[6];
+    if (!dlt_pose(pts2d, pts3d, K, pn, R, t)) return -2;
+    pvnet_matrix_to_angle_axis(R, x0);
+    x0[3] = t[0]; x0[4] = t[1]; x0[5] = t[2];
+    int it = pvnet_pnp_refine(pts2d, pts3d, nullptr, K, x0, result_rt, pn, 200, nullptr);
+    if (it >= 0 && wgt2d) {  // uncertainty-driven PnP: the weighted problem from the unweighted optimum
+        std::memcpy(x0, result_rt, sizeof(x0));
+        const int it2 = pvnet_pnp_refine(pts2d, pts3d, wgt2d, K, x0, result_rt, pn, 200, nullptr);
+        it = it2 < 0 ? it2 : it + it2;
+    }
+    return it;
+}
+
+int pvnet_pnp_solve_batch(const double* pts2d, const double* pts3d, const double* wgt2d, const double* K,
+                          double* result_rt, int n, int pn) {
+    if (n < 0) return -1;
+    int bad = 0;
+    for (int i = 0; i < n; ++i) {
+        const int rc = pvnet_pnp_solve(pts2d + (size_t)i * pn * 2, pts3d, wgt2d ? wgt2d + (size_t)i * pn * 3 : nullptr, K,
+                                       result_rt + (size_t)i * 6, pn);
+        if (rc == -1) return -1;
+        if (rc < 0) {
+            ++bad;
+            for (int a = 0; a < 6; ++a) result_rt[(size_t)i * 6 + a] = 0.0;
+        }
+    }
+    return bad;
 }
 
 void pvnet_angle_axis_to_matrix(const double* aa, double* R) { rotation_and_right_jacobian(aa, R, nullptr); }

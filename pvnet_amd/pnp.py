@@ -34,6 +34,10 @@ def load_pnp_library() -> C.CDLL:
         lib.uncertainty_pnp.argtypes = [dp] * 6 + [C.c_int]
         lib.pvnet_pnp_refine.restype = C.c_int
         lib.pvnet_pnp_refine.argtypes = [dp] * 6 + [C.c_int, C.c_int, dp]
+        lib.pvnet_pnp_solve.restype = C.c_int
+        lib.pvnet_pnp_solve.argtypes = [dp] * 5 + [C.c_int]
+        lib.pvnet_pnp_solve_batch.restype = C.c_int
+        lib.pvnet_pnp_solve_batch.argtypes = [dp] * 5 + [C.c_int, C.c_int]
         lib.pvnet_angle_axis_to_matrix.restype = None
         lib.pvnet_angle_axis_to_matrix.argtypes = [dp, dp]
         lib.pvnet_matrix_to_angle_axis.restype = None
@@ -146,6 +150,13 @@ def pnp(points_3d, points_2d, camera_matrix, method="iterative", init=None, back
     points_2d = np.ascontiguousarray(points_2d, np.float64)
     K = np.asarray(camera_matrix, np.float64)
     assert points_3d.shape[0] == points_2d.shape[0], "points 3D and points 2D must have same number of vertices"
+    if init is None and backend == "native" and points_3d.shape[0] >= 6:  # linear start + LM in one native call
+        out = np.empty(6, np.float64)
+        Kc = np.ascontiguousarray(K)
+        rc = load_pnp_library().pvnet_pnp_solve(_dptr(points_2d), _dptr(points_3d), None, _dptr(Kc), _dptr(out),
+                                                points_3d.shape[0])
+        if rc >= 0:
+            return np.concatenate([rodrigues(out[:3]), out[3:, None]], 1)
     if init is None:
         R0, t0 = _dlt_pose(points_3d, points_2d, K)  # det(R0) > 0 fixes the sign of the homogeneous solution
         x0 = np.concatenate([rodrigues_inv(R0), t0])
@@ -173,6 +184,23 @@ def uncertainty_pnp_v2(points_2d, covars, points_3d, camera_matrix, backend="nat
     w = np.array([0.0 if c[0, 0] < 1e-5 else 1.0 / np.max(np.linalg.eigvalsh(c)) for c in covars])
     W = np.stack([w, np.zeros_like(w), w], 1)
     return uncertainty_pnp(points_2d, W, points_3d, camera_matrix, backend=backend)
+
+
+def pnp_batch(points_3d, points_2d, camera_matrix, weights_2d=None):
+    """``pnp`` (or, with ``weights_2d [n,pn,3]``, ``uncertainty_pnp``) for n images that share the object points, in
+    one native call: points_2d [n,pn,2] -> poses [n,3,4].  Images whose linear start is degenerate come back as zeros."""
+    p2 = np.ascontiguousarray(points_2d, np.float64)
+    p3 = np.ascontiguousarray(points_3d, np.float64)
+    Kc = np.ascontiguousarray(camera_matrix, np.float64)
+    n, pn = p2.shape[0], p2.shape[1]
+    assert p3.shape == (pn, 3) and p2.shape == (n, pn, 2)
+    Wc = None if weights_2d is None else np.ascontiguousarray(weights_2d, np.float64)
+    out = np.empty((n, 6), np.float64)
+    rc = load_pnp_library().pvnet_pnp_solve_batch(_dptr(p2), _dptr(p3), None if Wc is None else _dptr(Wc), _dptr(Kc),
+                                                  _dptr(out), n, pn)
+    if rc < 0:
+        raise RuntimeError("pvnet_pnp_solve_batch: bad arguments (needs >= 6 points per image)")
+    return np.stack([np.concatenate([rodrigues(o[:3]), o[3:, None]], 1) if np.any(o) else np.zeros((3, 4)) for o in out])
 
 
 # ---- metrics of Evaluator (evaluation_utils.py:75-134) -----------------------------------------------------

@@ -116,3 +116,40 @@ def test_native_lm_rejects_bad_arguments_and_survives_degenerate_input():
     assert lib.pvnet_pnp_refine(dp(z), dp(z), None, dp(np.ascontiguousarray(P.LINEMOD_K.ravel())), dp(init), dp(out), 9,
                                 10, None) == 0
     np.testing.assert_array_equal(out, init)
+
+
+def test_native_linear_start_and_batch_solve_match_the_numpy_scipy_path():
+    """pvnet_pnp_solve (native DLT + LM) against numpy DLT + scipy LM, and the batched entry against per-image calls"""
+    rng = np.random.default_rng(11)
+    X = rng.uniform(-0.08, 0.08, size=(9, 3))
+    x2, poses = [], []
+    for _ in range(16):
+        r = rng.normal(size=3)
+        r *= rng.uniform(0.1, 2.8) / np.linalg.norm(r)
+        pose = np.concatenate([P.rodrigues(r), np.array([[rng.uniform(-0.2, 0.2)], [rng.uniform(-0.2, 0.2)],
+                                                         [rng.uniform(0.5, 1.5)]])], 1)
+        poses.append(pose)
+        x2.append(P.project(X, pose, P.LINEMOD_K) + rng.normal(size=(9, 2)) * 0.4)
+    x2 = np.stack(x2)
+    batch = P.pnp_batch(X, x2, P.LINEMOD_K)
+    for i in range(16):
+        ref = P.pnp(X, x2[i], P.LINEMOD_K, backend="scipy")
+        np.testing.assert_allclose(P.pnp(X, x2[i], P.LINEMOD_K), ref, atol=2e-7)
+        np.testing.assert_allclose(batch[i], ref, atol=2e-7)
+        assert P.projection_2d_error(batch[i], poses[i], X, P.LINEMOD_K) < 2.0  # 0.4 px noise on 9 points
+    W = np.tile([1.0, 0.0, 1.0], (16, 9, 1))
+    W[:, 8] = [0.01, 0.0, 0.01]  # one key-point trusted 100x less
+    wb = P.pnp_batch(X, x2, P.LINEMOD_K, weights_2d=W)
+    for i in range(16):
+        np.testing.assert_allclose(wb[i], P.uncertainty_pnp(x2[i], W[i], X, P.LINEMOD_K, backend="scipy"), atol=2e-6)
+
+
+def test_native_solve_flags_degenerate_input():
+    import ctypes as C
+    lib = P.load_pnp_library()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    out = np.zeros(6)
+    K = np.ascontiguousarray(P.LINEMOD_K)
+    z2, z3 = np.zeros((9, 2)), np.zeros((9, 3))
+    assert lib.pvnet_pnp_solve(dp(z2), dp(z3), None, dp(K), dp(out), 5) == -1  # the linear start needs 6 points
+    assert lib.pvnet_pnp_solve(dp(z2), dp(z3), None, dp(K), dp(out), 9) < 0    # all points coincide

@@ -98,8 +98,7 @@ def main():
                 k = head(s, v)
                 if do_pnp:
                     kc = k.cpu().numpy().astype(np.float64)  # the step's one host sync (tools/demo.py:176)
-                    for i in range(b):
-                        pnp.pnp(X3, kc[i], pnp.LINEMOD_K)
+                    pnp.pnp_batch(X3, kc, pnp.LINEMOD_K)     # native DLT + LM for the b poses
                 return k
 
             def timed(fn, n):
