@@ -302,7 +302,11 @@ def main():
             "stage_ms": stage_ms,
         }
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(sets, a.cpu_seconds)
+            try:
+                res["cpu_baseline"] = cpu_baseline(sets, a.cpu_seconds)
+            except Exception as e:  # the reported baseline must never take the measured line down with it
+                res["cpu_baseline"] = {"value": None, "unit": "votings/s", "cores": usable_cores(), "kind": "port",
+                                       "sample": f"failed: {type(e).__name__}: {e}"}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     if dist is not None:
