@@ -1,5 +1,6 @@
 """Host PnP: known-answer tests on the reference's demo fixture -- pose in, key-points out, pose back."""
 import numpy as np
+import pytest
 
 from pvnet_amd import pnp as P
 
@@ -153,3 +154,27 @@ def test_native_solve_flags_degenerate_input():
     z2, z3 = np.zeros((9, 2)), np.zeros((9, 3))
     assert lib.pvnet_pnp_solve(dp(z2), dp(z3), None, dp(K), dp(out), 5) == -1  # the linear start needs 6 points
     assert lib.pvnet_pnp_solve(dp(z2), dp(z3), None, dp(K), dp(out), 9) < 0    # all points coincide
+
+
+def test_native_library_is_clean_under_asan_ubsan(tmp_path):
+    """pvnet_pnp.cpp + a 200-problem driver compiled with -fsanitize=address,undefined: any out-of-bounds access,
+    use of uninitialised stack, signed overflow or misaligned access aborts the run"""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cxx = shutil.which("g++")
+    if cxx is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "pnp_san")
+    cmd = [cxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-fno-omit-frame-pointer", "-I", os.path.join(root, "include"),
+           os.path.join(root, "pvnet_amd", "csrc", "pvnet_pnp.cpp"),
+           os.path.join(root, "tests", "native", "pnp_sanitizer_driver.cpp"), "-o", exe]
+    built = subprocess.run(cmd, capture_output=True, text=True)
+    if built.returncode != 0 and "sanitize" in built.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert built.returncode == 0, built.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "sanitized run done" in run.stdout
