@@ -12,3 +12,6 @@ python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 3000 $OUT/bench.jso
 ( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY -d $OUT/pmc_sq -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --streams 1 --prewarm-seconds 0 --no-cpu-baseline > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err )
 find $OUT -name "*.csv" | head -30
 ls -la $OUT/trace/* | head
+# matrix-pipe and LDS counters of the scoring kernel (own passes; never together with trace domains other than kernel-trace)
+( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_mfma -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --streams 1 --prewarm-seconds 0 --no-cpu-baseline > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err )
+( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 -d $OUT/pmc_lds -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --streams 1 --prewarm-seconds 0 --no-cpu-baseline > $OUT/pmc_lds.json 2> $OUT/pmc_lds.err )
