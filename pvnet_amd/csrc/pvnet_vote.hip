@@ -938,15 +938,15 @@ __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
             n += s_n[i];
         }
         const double det = a * d - bb * bb;
-        float ox = wx, oy = wy;
+        float rx = wx, ry = wy;  // refined point (the winner itself when the system is singular)
         if (n == 0 || det == 0.0 || !isfinite(det)) {
             status |= PVNET_S_SINGULAR;  // torch.gesv raises here (:511); we return the winner and flag it
         } else {
-            ox = (float)((double)wx + (d * r0 - bb * r1) / det);
-            oy = (float)((double)wy + (a * r1 - bb * r0) / det);
+            rx = (float)((double)wx + (d * r0 - bb * r1) / det);
+            ry = (float)((double)wy + (a * r1 - bb * r0) / det);
         }
-        P.out[bk * 2] = ox;
-        P.out[bk * 2 + 1] = oy;
+        P.out[bk * 2] = rx;
+        P.out[bk * 2 + 1] = ry;
         if (P.status) P.status[bk] = status;
     }
 }
