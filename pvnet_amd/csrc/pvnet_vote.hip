@@ -255,53 +255,50 @@ __global__ __launch_bounds__(64 * K1_WAVES) void mask_bits_kernel(VoteParams P) 
     small_stage_prio();
     const int bi = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __shared__ int s_cnt[K1_WAVES];
-    for (int sgi = blockIdx.x; sgi < P.nseg; sgi += gridDim.x) {  // (one trip unless the grid is persistent)
-        const int word0 = (sgi * K1_WAVES + wave) * K1_WORDS_PER_WAVE;
-        bool f[K1_WORDS_PER_WAVE];
+    const int word0 = (blockIdx.x * K1_WAVES + wave) * K1_WORDS_PER_WAVE;
+    bool f[K1_WORDS_PER_WAVE];
 #pragma unroll
-        for (int i = 0; i < K1_WORDS_PER_WAVE; ++i) {
-            const int p = (word0 + i) * 64 + lane;
-            bool v = false;
-            if (p < P.npix) {
-                int64_t off;
-                if (P.mask_linear) {
-                    off = (int64_t)bi * P.ms0 + p;
-                } else {
-                    const int y = p / P.w, x = p - y * P.w;
-                    off = (int64_t)bi * P.ms0 + (int64_t)y * P.ms1 + (int64_t)x * P.ms2;
-                }
-                if (DT == PVNET_MASK_LOGITS_F32) {  // fused torch.argmax(seg_pred, 1) (tools/demo.py:52): first maximum wins
-                    const float* sp = reinterpret_cast<const float*>(P.mask) + off;
-                    float best = sp[0];
-                    int arg = 0;
-                    for (int c = 1; c < P.num_classes; ++c) {
-                        const float x = sp[(int64_t)c * P.ms_c];
-                        if (x > best) { best = x; arg = c; }
-                    }
-                    v = (arg & 0xFF) != 0;  // then .byte() != 0 (ransac_voting_gpu.py:527)
-                } else {
-                    v = load_fg<DT>(P.mask, off);
-                }
+    for (int i = 0; i < K1_WORDS_PER_WAVE; ++i) {
+        const int p = (word0 + i) * 64 + lane;
+        bool v = false;
+        if (p < P.npix) {
+            int64_t off;
+            if (P.mask_linear) {
+                off = (int64_t)bi * P.ms0 + p;
+            } else {
+                const int y = p / P.w, x = p - y * P.w;
+                off = (int64_t)bi * P.ms0 + (int64_t)y * P.ms1 + (int64_t)x * P.ms2;
             }
-            f[i] = v;
+            if (DT == PVNET_MASK_LOGITS_F32) {  // fused torch.argmax(seg_pred, 1) (tools/demo.py:52): first maximum wins
+                const float* sp = reinterpret_cast<const float*>(P.mask) + off;
+                float best = sp[0];
+                int arg = 0;
+                for (int c = 1; c < P.num_classes; ++c) {
+                    const float x = sp[(int64_t)c * P.ms_c];
+                    if (x > best) { best = x; arg = c; }
+                }
+                v = (arg & 0xFF) != 0;  // then .byte() != 0 (ransac_voting_gpu.py:527)
+            } else {
+                v = load_fg<DT>(P.mask, off);
+            }
         }
-        int cnt = 0;
+        f[i] = v;
+    }
+    int cnt = 0;
 #pragma unroll
-        for (int i = 0; i < K1_WORDS_PER_WAVE; ++i) {
-            const unsigned long long m = __ballot(f[i]);
-            if (lane == 0 && word0 + i < P.words) P.bits[(size_t)bi * P.words + word0 + i] = m;
-            cnt += __popcll(m);
-        }
-        if (lane == 0) s_cnt[wave] = cnt;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int t = 0;
-            for (int i = 0; i < K1_WAVES; ++i) t += s_cnt[i];
-            P.seg[bi * P.nseg + sgi] = t;   // foreground pixels of this 4096-pixel segment (thinned by K1b)
-            P.seg0[bi * P.nseg + sgi] = t;  // ... as the mask has them (tn0 = their sum)
-        }
-        if (sgi + (int)gridDim.x < P.nseg) __syncthreads();  // s_cnt is reused by the next trip
+    for (int i = 0; i < K1_WORDS_PER_WAVE; ++i) {
+        const unsigned long long m = __ballot(f[i]);
+        if (lane == 0 && word0 + i < P.words) P.bits[(size_t)bi * P.words + word0 + i] = m;
+        cnt += __popcll(m);
+    }
+    __shared__ int s_cnt[K1_WAVES];
+    if (lane == 0) s_cnt[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int i = 0; i < K1_WAVES; ++i) t += s_cnt[i];
+        P.seg[bi * P.nseg + blockIdx.x] = t;   // foreground pixels of this 4096-pixel segment (thinned by K1b)
+        P.seg0[bi * P.nseg + blockIdx.x] = t;  // ... as the mask has them (tn0 = their sum)
     }
 }
 
@@ -1173,8 +1170,7 @@ int launch_score(const VoteParams& P, dim3 grid, hipStream_t s) {
 }
 
 int launch_mask_bits(const VoteParams& P, hipStream_t s) {
-    const int k1g = env_int("PVNET_K1_BLOCKS_PER_IMAGE", 0);  // > 0: persistent grid, blocks walk the segments
-    dim3 grid(k1g > 0 && k1g < P.nseg ? k1g : P.nseg, P.b);
+    dim3 grid(P.nseg, P.b);
     switch (P.mask_dtype) {
         case PVNET_MASK_U8: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_U8>, grid, dim3(64 * K1_WAVES), 0, s, P); break;
         case PVNET_MASK_I16: hipLaunchKernelGGL(mask_bits_kernel<PVNET_MASK_I16>, grid, dim3(64 * K1_WAVES), 0, s, P); break;

@@ -554,7 +554,6 @@ def test_concurrent_streams_reproduce_serial_results():
 
 
 @pytest.mark.parametrize("knobs", [
-    {"PVNET_K1_BLOCKS_PER_IMAGE": "4"},                       # persistent mask-kernel grid
     {"PVNET_SCORE_WGS_PER_CU": "0"}, {"PVNET_SCORE_WGS_PER_CU": "2"},  # one workgroup per item / a small persistent grid
     {"PVNET_SCORE_CHUNK": "64"}, {"PVNET_SCORE_CHUNK": "256"},  # pixels per count row (2 and 8..16 tiles per item)
     {"PVNET_SCORE_HPL": "2"}, {"PVNET_SCORE_HPL": "4"},        # fewer hypotheses per work item (MH = 2, 4)
