@@ -575,3 +575,46 @@ def test_launch_knobs_do_not_change_results(knobs, monkeypatch):
     assert torch.equal(d_l["counts"], counts_l) and torch.equal(out_l, ref_l)
     assert torch.equal(d_f["counts"], counts_f) and torch.equal(out_f, ref_f)
 
+
+
+def test_hd_frame_two_objects_literal_vs_c_oracle():
+    """a 1080 x 1920 frame (6.7x the pixels of the headline shape: 507 segments per image), one small and one large
+    object: compaction order, hypotheses and inlier counts must still equal the C oracle's exactly"""
+    h, w, vn, hn = 1080, 1920, 5, 256
+    rng = np.random.default_rng(77)
+    mask = np.zeros((2, h, w), np.uint8)
+    ys, xs = np.mgrid[0:h, 0:w]
+    mask[0][(ys - 900) ** 2 + (xs - 1700) ** 2 < 30 ** 2] = 1      # small object in the last rows
+    mask[1][(ys - 400) ** 2 + (xs - 800) ** 2 < 95 ** 2] = 1       # tn ~ 28 k: just under max_num
+    kpts = np.stack([np.stack([rng.uniform(1650, 1750, vn), rng.uniform(850, 950, vn)], 1),
+                     np.stack([rng.uniform(700, 900, vn), rng.uniform(300, 500, vn)], 1)]).astype(np.float32)
+    planar = np.zeros((2, 2 * vn, h, w), np.float32)
+    for bi in range(2):
+        planar[bi] = synth.field_from_keypoints(mask[bi].astype(bool), kpts[bi])
+        fg = mask[bi].astype(bool)
+        planar[bi][:, fg] += rng.normal(size=(2 * vn, int(fg.sum()))).astype(np.float32) * 0.05  # noisy directions
+    m, v = to_dev(mask, planar)
+    out, dbg = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=0.99, seed=5, literal=True, return_debug=True)
+    ref, wi, wc = cref.vote_v3(O.foreground(mask), synth.planar_to_vertex_view(planar), hn, 0.99, seed=5,
+                               return_winners=True)
+    assert dbg["tn"].cpu().numpy().tolist() == [int(mask[0].sum()), int(mask[1].sum())]
+    np.testing.assert_array_equal(dbg["win"][:, :, 0].cpu().numpy(), wi)
+    np.testing.assert_array_equal(dbg["win"][:, :, 1].cpu().numpy(), wc)
+    assert np.abs(out.cpu().numpy() - ref).max() < TOL_PX
+    fast = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=0.99, seed=5).cpu().numpy()
+    assert np.abs(fast - kpts).max() < 3.0  # 0.05 noise on unit vectors, key-points up to ~100 px from the object
+    assert np.abs(fast - ref).max() < 5e-2  # same draw, winners may differ between near-ties; refined points agree
+
+
+def test_single_hypothesis_and_single_keypoint():
+    """hn = 1, vn = 1: one pixel pair decides; the layer returns its refined intersection (or flags a degenerate pair)"""
+    mask, planar, _, vnp = small_batch(b=4, first=1400, h=90, w=120, radius=14)
+    planar = planar[:, :2].copy()
+    m, v = to_dev(mask, planar)
+    out, st, dbg = voting.ransac_voting_layer_v3(m, v, 1, inlier_thresh=0.99, seed=3, literal=True, return_status=True,
+                                                 return_debug=True)
+    ref, wi, wc = cref.vote_v3(O.foreground(mask), synth.planar_to_vertex_view(planar), 1, 0.99, seed=3,
+                               return_winners=True)
+    np.testing.assert_array_equal(dbg["win"][:, :, 1].cpu().numpy(), wc)
+    ok = (st.cpu().numpy() == 0)
+    assert np.abs(out.cpu().numpy() - ref)[ok].max() < TOL_PX
