@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PVNET_VOTE_ABI_VERSION 2
+#define PVNET_VOTE_ABI_VERSION 3
 
 /* negative library error codes */
 #define PVNET_E_BADARG      (-1)   /* null pointer / non-positive size / unsupported dtype or stride */
@@ -69,8 +69,9 @@ typedef struct PvnetVoteLayout {
     size_t off_ctrl;        /* int32 [b][8]: tn0, tn, status, item_base, nchunks, -, -, -  ; then [8] global */
     size_t off_bits;        /* uint64 [b][words]           foreground (after subsampling) bit mask          */
     size_t off_pix;         /* int32  [b][cap]             linear pixel index y*w+x of compacted pixel t    */
-    size_t off_rec;         /* float4 [b][vn][cap]         record (x, y, My, -Mx), M = 2^90 * direction (exact scaling;
-                                                           literal mode: (x, y, ux, uy)) -- the only per-pixel data */
+    size_t off_rec;         /* float4 [b][vn][cap]         record (x, y, ux, uy): pixel and its RAW direction for the
+                                                           key-point (fast mode: zero when |u| < 1e-6, which never votes,
+                                                           kernel.cu:121) -- the only per-pixel data, same in both modes */
     size_t off_hyp;         /* float2 [b][vn][hn_pad]      hypotheses                                       */
     size_t off_partial;     /* uint16 [b][vn][max_chunks][hn_pad]  per-chunk inlier counts                  */
     size_t off_counts;      /* int32  [b][vn][hn_pad]      inlier count of every hypothesis                 */
@@ -140,12 +141,25 @@ int pvnet_vote_v3_profiled(const void* mask, int mask_dtype, const int64_t mask_
                            float* out_kpts, int32_t* out_status,
                            void* workspace, size_t workspace_bytes, void* stream, float* stage_ms);
 
+/* Profiling only, like pvnet_vote_v3_profiled: runs the whole path once, then re-launches ONE stage (PVNET_STAGE_*)
+ * `repeats` times back to back on that workspace, bracketed by a single hipEvent pair on `stream`; synchronises.
+ * *avg_ms (host) = elapsed / repeats: the stage's kernel duration as a kernel trace reports it (plus the ~1.5 us
+ * dependent-launch boundary), free of host launch gaps and cold clocks.  bench.py's roofline uses it. */
+int pvnet_vote_v3_stage_repeat(const void* mask, int mask_dtype, const int64_t mask_strides[3],
+                               const float* vertex, const int64_t vertex_strides[5],
+                               int b, int h, int w, int vn, int hn,
+                               float inlier_thresh, int min_num, int max_num,
+                               uint64_t seed, int image_base, const int32_t* idxs, uint32_t flags,
+                               float* out_kpts, int32_t* out_status,
+                               void* workspace, size_t workspace_bytes, void* stream,
+                               int stage, int repeats, float* avg_ms);
+
 /* Epilogues of the reference's sibling functions.  Both run on the WORKSPACE of a preceding pvnet_vote_v3 call with
  * the same (b,h,w,vn,hn,max_num) on the same stream (they read its compacted pixel lists, hypotheses and counts).
  *
  * pvnet_vote_confidence: ransac_voting_layer_v5's second output (ransac_voting_gpu.py:846-850): out_conf[b,vn] =
  *   fraction of the image's kept pixels whose direction points at kpts[b,vn,2] within `thresh` (0.999 there).
- *   vote_flags = the flags of that pvnet_vote_v3 call (its PVNET_F_LITERAL bit decides the record format). */
+ *   vote_flags: ignored since ABI 3 (records hold the raw direction in both scoring modes); kept for call compatibility. */
 int pvnet_vote_confidence(const float* kpts, float thresh, float* out_conf, uint32_t vote_flags, int b, int h, int w,
                           int vn, int hn, int max_num, void* workspace, size_t workspace_bytes, void* stream);
 /* pvnet_vote_distribution: estimate_voting_distribution_with_mean's epilogue (ransac_voting_gpu.py:389-404):
@@ -177,6 +191,11 @@ int pvnet_voting_for_hypothesis(const float* direct, const float* coords, const 
 /* ABI / build identification (host-only) */
 int pvnet_vote_abi_version(void);
 const char* pvnet_vote_build_info(void);
+
+/* Host-only.  The PVNET_* tuning environment variables are read ONCE, at the first call into
+ * the library -- never on the launch path; this re-reads them (tests and the tuning tools change them in-process).
+ * Knobs re-shape grids and work items, never results. */
+void pvnet_vote_tuning_reload(void);
 
 #ifdef __cplusplus
 }

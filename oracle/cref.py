@@ -69,8 +69,10 @@ def voting_for_hypothesis(direct, coords, hyp, inliers, thresh):
     return inliers
 
 
-def vote_v3(fg, vertex, hn, thresh=0.999, min_num=5, max_num=30000, seed=0, idxs=None, return_winners=False):
-    """fg [b,h,w] bool/uint8, vertex [b,h,w,vn,2] float32 with ANY strides (multiples of 4 bytes)."""
+def vote_v3(fg, vertex, hn, thresh=0.999, min_num=5, max_num=30000, seed=0, idxs=None, return_winners=False,
+            image_base=0):
+    """fg [b,h,w] bool/uint8, vertex [b,h,w,vn,2] float32 with ANY strides (multiples of 4 bytes); image_base = global
+    index of image 0 (its RNG stream), as the product's argument of the same name."""
     fg = np.ascontiguousarray(fg, np.uint8)
     assert vertex.dtype == np.float32
     b, h, w, vn, _ = vertex.shape
@@ -83,8 +85,9 @@ def vote_v3(fg, vertex, hn, thresh=0.999, min_num=5, max_num=30000, seed=0, idxs
         idxs = np.ascontiguousarray(np.broadcast_to(idxs, (b, hn, vn, 2)), np.int32)
         ip = _p(idxs, C.c_int32)
     base = C.cast(vertex.ctypes.data, C.POINTER(C.c_float))
-    lib().ref_vote_v3(_p(fg, C.c_uint8), base, vs, b, h, w, vn, int(hn), C.c_float(thresh), int(min_num),
-                      int(max_num), C.c_uint64(seed), ip, _p(out, C.c_float), _p(wi, C.c_int32), _p(wc, C.c_int32))
+    lib().ref_vote_v3_base(_p(fg, C.c_uint8), base, vs, b, h, w, vn, int(hn), C.c_float(thresh), int(min_num),
+                           int(max_num), C.c_uint64(seed), int(image_base), ip, _p(out, C.c_float), _p(wi, C.c_int32),
+                           _p(wc, C.c_int32))
     return (out, wi, wc) if return_winners else out
 
 

@@ -141,10 +141,13 @@ static __thread size_t tl_cap[5];
  * vertex element (bi,y,x,k,c) at vertex[bi*vs[0]+y*vs[1]+x*vs[2]+k*vs[3]+c*vs[4]] (strides in elements);
  * idxs: NULL (counter RNG) or [b,hn,vn,2]; out [b,vn,2]; win_idx/win_cnt [b,vn] optional.
  * Refinement accumulates in float64 (the "oracle32 + f64 LSQ" flavour of the numpy oracle). Returns 0. */
-int ref_vote_v3(const uint8_t* fg, const float* vertex, const int64_t* vs, int b, int h, int w, int vn, int hn,
-                float thresh, int min_num, int max_num, uint64_t seed, const int32_t* idxs, float* out,
-                int32_t* win_idx_out, int32_t* win_cnt_out) {
+/* image_base: global index of image 0 of this call -- the RNG stream of image bi is image_base + bi, as the product's
+ * `image_base` argument (include/pvnet_vote.h): lets a checker vote the images of a batch one by one. */
+int ref_vote_v3_base(const uint8_t* fg, const float* vertex, const int64_t* vs, int b, int h, int w, int vn, int hn,
+                     float thresh, int min_num, int max_num, uint64_t seed, int image_base, const int32_t* idxs,
+                     float* out, int32_t* win_idx_out, int32_t* win_cnt_out) {
     for (int bi = 0; bi < b; ++bi) {
+        const uint32_t stream = (uint32_t)(image_base + bi);
         const uint8_t* m = fg + (size_t)bi * h * w;
         float* o = out + (size_t)bi * vn * 2;
         for (int i = 0; i < vn * 2; ++i) o[i] = 0.f;
@@ -164,7 +167,7 @@ int ref_vote_v3(const uint8_t* fg, const float* vertex, const int64_t* vs, int b
             for (int x = 0; x < w; ++x) {
                 int p = y * w + x;
                 if (!m[p]) continue;
-                if (thr < (1ull << 32) && (uint64_t)ref_rng_u32(seed, TAG_SUB, (uint32_t)bi, (uint32_t)p) >= thr)
+                if (thr < (1ull << 32) && (uint64_t)ref_rng_u32(seed, TAG_SUB, stream, (uint32_t)p) >= thr)
                     continue;
                 coords[tn * 2] = (float)x; coords[tn * 2 + 1] = (float)y;
                 const float* v = vertex + bi * vs[0] + y * vs[1] + x * vs[2];
@@ -178,7 +181,7 @@ int ref_vote_v3(const uint8_t* fg, const float* vertex, const int64_t* vs, int b
         int32_t* ix = (int32_t*)scratch(&tl_buf[2], &tl_cap[2], sizeof(int32_t) * 2 * (size_t)hn * vn);  /* :547 */
         for (int i = 0; i < hn * vn * 2; ++i)
             ix[i] = idxs ? idxs[(size_t)bi * hn * vn * 2 + i]
-                         : (int32_t)(((uint64_t)ref_rng_u32(seed, TAG_HYP, (uint32_t)bi, (uint32_t)i) * (uint64_t)tn) >> 32);
+                         : (int32_t)(((uint64_t)ref_rng_u32(seed, TAG_HYP, stream, (uint32_t)i) * (uint64_t)tn) >> 32);
         float* hyp = (float*)scratch(&tl_buf[3], &tl_cap[3], sizeof(float) * 2 * (size_t)hn * vn);
         int32_t* counts = (int32_t*)scratch(&tl_buf[4], &tl_cap[4], sizeof(int32_t) * (size_t)hn * vn);
         ref_generate_hypothesis(direct, coords, ix, hyp, tn, vn, hn);               /* :554 */
@@ -208,4 +211,11 @@ int ref_vote_v3(const uint8_t* fg, const float* vertex, const int64_t* vs, int b
         }
     }
     return 0;
+}
+
+int ref_vote_v3(const uint8_t* fg, const float* vertex, const int64_t* vs, int b, int h, int w, int vn, int hn,
+                float thresh, int min_num, int max_num, uint64_t seed, const int32_t* idxs, float* out,
+                int32_t* win_idx_out, int32_t* win_cnt_out) {
+    return ref_vote_v3_base(fg, vertex, vs, b, h, w, vn, hn, thresh, min_num, max_num, seed, 0, idxs, out,
+                            win_idx_out, win_cnt_out);
 }

@@ -16,15 +16,15 @@
 //                     every kept pixel its slot; one thread per kept pixel gathers its vn direction vectors
 //                     straight from the strided field (planar in practice -> consecutive lanes read
 //                     consecutive addresses) and writes ONE float4 record per (pixel, key-point):
-//                     (x, y, My, -Mx) with M = 2^90 * direction                                        [HBM read]
+//                     (x, y, ux, uy), the raw direction                                                 [HBM read]
 //   K3 hypotheses     one thread per (image, kp, h): two pixel draws (counter RNG or caller idxs), 2x2 solve in
 //                     the reference's float32 order; also writes each hypothesis as a bf16x3 MFMA operand column;
 //                     one extra block per image plans the scoring work items
 //   K4 score          DOMINANT.  Fast mode (score_mfma_kernel): the vote is two 3-term fp32 dot products and a
 //                     compare; every operand is split into three bf16 parts, so each dot product is ONE
 //                     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (fp32-equivalent accuracy, measured), and
-//                     the lane that owns the hypothesis counts its 16 results as t = clamp(dt - |cr|) (the 2^90
-//                     record scaling makes the clamp an exact 1.0f / 0) summed two at a time by a wrapping
+//                     the lane that owns the hypothesis counts its 16 results as t = clamp(dt - |cr|) (the
+//                     per-record 2^60 scaling makes the clamp an exact 1.0f / 0) summed two at a time by a wrapping
 //                     v_add3_u32: 2 MFMAs + 1.5 VALU ops per test (vote8).  Records are expanded and staged in
 //                     LDS once per work item.
 //                     Literal mode (score_kernel<HPL,true>): "lane owns hypotheses" on the VALU in the
@@ -82,7 +82,7 @@ struct VoteParams {
     int mask_dtype, mask_linear, num_classes;
     const float* vertex;
     int64_t vs0, vs1, vs2, vs3, vs4;
-    int b, h, w, vn, hn, npix, words, cap, chunk, max_chunks, hpl, hgroups, hn_pad, wg_g, wg_s, mode;
+    int b, h, w, vn, hn, npix, words, cap, chunk, max_chunks, hpl, hgroups, hn_pad, wg_g, wg_s, mode, score_xcd;
     float thresh, tau;
     int min_num, max_num;
     uint64_t seed;
@@ -140,11 +140,18 @@ __device__ __forceinline__ bool inlier_literal(float cx, float cy, float nx, flo
 
 // Fast form of the same predicate.  With tau = sqrt(1 - thresh^2) / thresh (0 < thresh < 1) and d = h - c:
 //     cos(angle(d, u)) > thresh   <=>   |d x u| < tau * (d . u)          (scale-invariant in |u|: no normalisation)
-// A record carries M = 2^90 * u; with T = tau * M the quantity  s = T.d - |M x d|  is 2^90 times the margin, so any
-// non-zero float32 margin is >= 1 in magnitude and the last fma's CLAMP output modifier turns s into exactly 1.0f
-// (votes) or 0.0f (does not) -- the vote IS the arithmetic result: no compare, no carry, no scalar op.
-// Zero directions (|u| < 1e-6, kernel.cu:121) are stored as zero records and never vote; a hypothesis that sits
-// exactly on a pixel gives s = 0 and does not vote either, as in the reference.
+// The vote is taken on M = 2^k * u, with the power of two chosen PER RECORD so that max(|Mx|, |My|) lies in
+// [2^60, 2^61) (vote_scale: an exact exponent shift, so the decision is that of u itself).  With T = tau * M the
+// quantity  s = T.d - |M x d|  is then ~2^60 times the margin: any non-zero float32 margin is >= 1 in magnitude
+// (a difference of two floats is a multiple of the smaller one's ulp, and at the threshold both terms are
+// ~2^60 * tau * |d| >= 2^23 for any |d| >= 1e-9 px at thresh <= 0.9999), so a CLAMP output modifier turns s into
+// exactly 1.0f (votes) or 0.0f (does not) -- the vote IS the arithmetic result: no compare, no carry, no scalar op.
+// Because the scale follows the record, un-normalised fields (|u| from 1e-6 up to 2^60) behave like unit ones, and a
+// term overflows float32 only for hypotheses farther than 2^67 px from the image (the reference's own 1e-6
+// determinant gate keeps them below ~1e15 px); a NaN / Inf direction gives NaN margins, which the clamp turns into 0:
+// no vote, as the reference's comparison with NaN decides.
+// Zero directions (|u| < 1e-6, kernel.cu:121) are stored as zero records by K2 in fast mode and never vote; a
+// hypothesis that sits exactly on a pixel gives s = 0 and does not vote either, as in the reference.
 // The subtraction d = h - c is folded into per-pixel constants ("expanded form"):
 //     cr = hx*My - hy*Mx - Ec,  Ec = cx*My - cy*Mx          s = hx*Tx + hy*Ty - Ed - |cr|,  Ed = cx*Tx + cy*Ty
 // = 5 VALU ops (4 fma + 1 sub with |.|) + 1 add to accumulate.  Coordinates are taken relative to a per-image
@@ -152,19 +159,25 @@ __device__ __forceinline__ bool inlier_literal(float cx, float cy, float nx, flo
 // against float64 arithmetic on the benchmark data (tools/precision_study.py) this form decides 3e-8 of the pair
 // tests differently, the un-expanded 7-op form 1e-8, and the reference's own float32 sqrt/divide order 6e-7 (the
 // tan-based test resolves ~1e-7 rad at the threshold, cos-based float32 only ~1e-6: cos is flat where tan is steep).
-constexpr float kVoteScale = 0x1p90f;
-constexpr float kVoteUnscale = 0x1p-90f;
-// raw direction of a record: fast records hold (x, y, My, -Mx) with M = 2^90 * u (an exact power-of-two scaling, so
-// u comes back bit for bit; directions below 1e-6 were stored as zero and count as zero everywhere); literal
-// records hold (x, y, ux, uy) themselves.
-template <bool LITERAL>
-__device__ __forceinline__ float2 rec_dir(float4 q) {
-    return LITERAL ? make_float2(q.z, q.w) : make_float2(-q.w * kVoteUnscale, q.z * kVoteUnscale);
+//
+// Records are (x, y, ux, uy) in both modes: the raw direction as the field holds it (fast mode: zeroed when
+// |u| < 1e-6).  Everything that needs u itself -- hypothesis generation, the least-squares normals, the confidence
+// epilogue -- reads it back bit for bit.
+__device__ __forceinline__ float2 rec_dir(float4 q) { return make_float2(q.z, q.w); }
+// the power of two that brings max(|ux|, |uy|) into [2^60, 2^61); any finite value for a zero / denormal direction
+// (its products are zero whatever the scale) and for Inf / NaN (whose products are NaN whatever the scale)
+__device__ __forceinline__ float vote_scale(float ux, float uy) {
+    const float m = fmaxf(fabsf(ux), fabsf(uy));
+    const uint32_t e = (__float_as_uint(m) >> 23) & 0xFFu;   // biased exponent of m
+    uint32_t f = 314u - e;                                   // 127 + 60 - (e - 127)
+    f = f > 254u ? 254u : f;
+    return __uint_as_float(f << 23);
 }
 // per-pixel constants as staged in LDS: a = (My, -Mx, -Ec, Tx) [ds_read_b128], b = (Ty, -Ed) [ds_read_b64]
 __device__ __forceinline__ void make_pixrec(float4 q, float tau, float ox, float oy, float4& a, float2& b) {
     const float cx = q.x - ox, cy = q.y - oy;  // exact: integer pixel coordinates
-    const float My = q.z, nMx = q.w;
+    const float sc = vote_scale(q.z, q.w);
+    const float My = q.w * sc, nMx = -q.z * sc;  // exact: a power-of-two scaling
     const float2 tq = make_float2(tau * -nMx, tau * My);  // T = tan(acos(thresh)) * M
     const float Ec = fmaf(cy, nMx, cx * My);
     const float Ed = fmaf(cy, tq.y, cx * tq.x);
@@ -417,9 +430,8 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
                 P.rec[o] = make_float4((float)x, (float)y, ux[kk], uy[kk]);
             } else {
                 const float n1 = __builtin_sqrtf(fmaf(uy[kk], uy[kk], ux[kk] * ux[kk]));
-                const float sc = (n1 <= kF1e6) ? 0.f : kVoteScale;  // zero direction never votes (:121)
-                const float Mx = ux[kk] * sc, My = uy[kk] * sc;
-                P.rec[o] = make_float4((float)x, (float)y, My, -Mx);
+                const bool dead = n1 <= kF1e6;  // zero direction never votes (:121): stored as a zero record
+                P.rec[o] = make_float4((float)x, (float)y, dead ? 0.f : ux[kk], dead ? 0.f : uy[kk]);
             }
         }
     };
@@ -552,7 +564,7 @@ __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
         }
         const float4 q0 = P.rec[((size_t)bi * P.vn + k) * P.cap + t0];  // (x, y, direction) of the two pixels
         const float4 q1 = P.rec[((size_t)bi * P.vn + k) * P.cap + t1];
-        const float2 d0 = rec_dir<LITERAL>(q0), d1 = rec_dir<LITERAL>(q1);
+        const float2 d0 = rec_dir(q0), d1 = rec_dir(q1);
         hyp_intersect(d0.x, d0.y, q0.x, q0.y, d1.x, d1.y, q1.x, q1.y, hx, hy);
     }
     P.hyp[((size_t)bi * P.vn + k) * P.hn_pad + h] = make_float2(hx, hy);
@@ -591,6 +603,21 @@ __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
 // ~139 M VALU wave-instructions in ~150 us = ~91 % of the 2-cycles-per-instruction bound at the 1.97 GHz it
 // sustains (profiles/r01_streamk_experiment.txt), so what is left is the op count, not the schedule.
 // ------------------------------------------------------------------------------------------------------------
+// Work items of a scoring launch owned by this workgroup.  Workgroups go to the 8 XCDs round-robin by linear id
+// (observed, for speed only: MI355X_MICROARCH.md "Workgroup dispatch"), and K3 plans the items in (image, key-point,
+// pixel group) order, so with score_xcd every XCD takes one contiguous eighth of the list: the B-operand columns and
+// records of an (image, key-point) are then fetched through ONE L2 instead of once per XCD.  Any placement gives the
+// same result -- the mapping is a permutation of items over workgroups.
+struct ItemRange { int first, end, step; };
+__device__ __forceinline__ ItemRange my_items(const VoteParams& P, int total) {
+    if (P.score_xcd && (gridDim.x & 7u) == 0 && gridDim.x >= 8) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int lo = (int)((long long)total * x >> 3), hi = (int)((long long)total * (x + 1) >> 3);
+        return {lo + j, hi, (int)(gridDim.x >> 3)};
+    }
+    return {(int)blockIdx.x, total, (int)gridDim.x};
+}
+
 constexpr int NB = 4;  // pixels per inner-loop step (4 ds_read_b128 + 4 ds_read_b64 in flight)
 
 template <int HPL, bool LITERAL>
@@ -605,7 +632,8 @@ __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
     const int32_t* __restrict__ ctrl = P.ctrl;
     const int total = ctrl[P.b * CTRL_STRIDE];
 
-    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    const ItemRange ir = my_items(P, total);
+    for (int item = ir.first; item < ir.end; item += ir.step) {
         const int4 desc = P.items[item];  // (image, key-point, chunk group, hypothesis slice), planned by K3
         const int bi = desc.x, k = desc.y, cg = desc.z, hq = desc.w;
         const int nch = ctrl[bi * CTRL_STRIDE + C_NCHUNKS];
@@ -683,8 +711,8 @@ __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
 // ------------------------------------------------------------------------------------------------------------
 constexpr int TILE_U4 = 128;  // uint4 per 32-pixel tile: A_cr rows (32 x 2) then A_dt rows (32 x 2)
 
-// Eight votes of the lane's hypothesis, 1.5 plain VALU operations per test.  The records carry M = 2^90 * direction,
-// so any non-zero margin is >= 1 in magnitude and the clamp output modifier turns t = clamp(dt - |cr|) into exactly
+// Eight votes of the lane's hypothesis, 1.5 plain VALU operations per test.  The staged rows carry M = 2^k * direction with
+// max(|Mx|, |My|) in [2^60, 2^61) (vote_scale), so any non-zero margin is >= 1 in magnitude and the clamp output modifier turns t = clamp(dt - |cr|) into exactly
 // 1.0f or 0.0f (NaN -> 0), i.e. the bit pattern 0x3F800000 or 0: no compare, no SGPR mask, no carry chain.  v_add3_u32
 // then sums TWO of them per instruction into a 32-bit integer that is allowed to wrap:
 //     acc = n * 0x3F800000 mod 2^32 = ((127 n) mod 512) << 23,
@@ -729,7 +757,8 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const uint4* lbase = s_t + col * 2 + half;  // this lane's 16 bytes of every A row block
 
-    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    const ItemRange ir = my_items(P, total);
+    for (int item = ir.first; item < ir.end; item += ir.step) {
         const int4 desc = P.items[item];  // (image, key-point, chunk group, hypothesis slice), planned by K3
         const int bi = desc.x, k = desc.y, cg = desc.z, hq = desc.w;
         const int tn = ctrl[bi * CTRL_STRIDE + C_TN];
@@ -896,7 +925,7 @@ __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
 #pragma unroll 4
     for (int t = threadIdx.x; t < tn; t += RT) {
         const float4 q = P.rec[bk * P.cap + t];
-        const float2 u = rec_dir<LITERAL>(q);
+        const float2 u = rec_dir(q);
         bool in;
         if (LITERAL) {
             in = inlier_literal(q.x, q.y, u.x, u.y, wx, wy, P.thresh);
@@ -906,8 +935,8 @@ __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
             make_pixrec(q, P.tau, ox, oy, ra, rb);
             in = vote_expanded(ra, rb, wx - ox, wy - oy) > 0.5f;  // the very predicate that scored
         }
-        const double wgt = in ? 1.0 : 0.0;  // predicated, not branched
-        const double nx = (double)u.y * wgt, ny = -(double)u.x * wgt;  // normal = (dy, -dx) (:580-581)
+        // predicated, not branched; a select, not a product: a NaN / Inf direction never votes and must not leak
+        const double nx = in ? (double)u.y : 0.0, ny = in ? -(double)u.x : 0.0;  // normal = (dy, -dx) (:580-581)
         const double bv = nx * ((double)q.x - (double)wx) + ny * ((double)q.y - (double)wy);
         a += nx * nx;
         bb += nx * ny;
@@ -953,7 +982,6 @@ __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
 // ------------------------------------------------------------------------------------------------------------
 // ransac_voting_layer_v5's extra output (ransac_voting_gpu.py:846-850): fraction of the image's kept pixels that
 // vote (literal float32 test, threshold `thresh`, 0.999 in the reference) for the given points.
-template <bool LITERAL>
 __global__ __launch_bounds__(256) void confidence_kernel(VoteParams P, const float* __restrict__ pts, float thresh,
                                                          float* __restrict__ conf) {
     const int k = blockIdx.x, bi = blockIdx.y;
@@ -965,7 +993,7 @@ __global__ __launch_bounds__(256) void confidence_kernel(VoteParams P, const flo
     if (live)
         for (int t = threadIdx.x; t < tn; t += 256) {
             const float4 q = P.rec[bk * P.cap + t];
-            const float2 u = rec_dir<LITERAL>(q);
+            const float2 u = rec_dir(q);
             n += inlier_literal(q.x, q.y, u.x, u.y, px, py, thresh) ? 1 : 0;
         }
     n = wave_reduce_add(n);
@@ -1133,16 +1161,36 @@ int env_int(const char* name, int dflt) {
     return (s && *s) ? atoi(s) : dflt;
 }
 
-int num_cus() {
-    static int cached[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (cached[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cached[dev] = n;
-    }
-    return cached[dev];
+// Tuning knobs.  The environment is read ONCE, at the first call into the library, never on
+// the launch path; pvnet_vote_tuning_reload() (host-only, for tests and the tuning tools) reads it again.  A value of
+// -1 means "not set: use the shape-dependent default".
+struct Tuning {
+    int score_mode;     // PVNET_SCORE_MODE        1: matrix-pipe scoring in fast mode, 0: the 6-op VALU kernel
+    int wgs_per_cu;     // PVNET_SCORE_WGS_PER_CU  scoring workgroups launched per CU (0: one per work item)
+    int hpl;            // PVNET_SCORE_HPL         hypotheses per lane of the VALU kernel / MFMA tiles per wave
+    int chunk;          // PVNET_SCORE_CHUNK       pixels per count row
+    int compact_kg;     // PVNET_COMPACT_KG        key-points per compaction block
+    int score_xcd;      // PVNET_SCORE_XCD         1: contiguous eighths of the work-item list per XCD (L2 affinity)
+    int dev_stages;     // PVNET_DEV_STAGES        development aid: bit mask of the stages to launch
+    int cus;            // compute units of the device (all GPUs of a node are the same part)
+};
+void load_tuning(Tuning& t) {
+    t.score_mode = env_int("PVNET_SCORE_MODE", 1);
+    t.wgs_per_cu = env_int("PVNET_SCORE_WGS_PER_CU", 8);
+    t.hpl = env_int("PVNET_SCORE_HPL", -1);
+    t.chunk = env_int("PVNET_SCORE_CHUNK", -1);
+    t.compact_kg = env_int("PVNET_COMPACT_KG", 3);
+    t.score_xcd = env_int("PVNET_SCORE_XCD", 1);
+    t.dev_stages = env_int("PVNET_DEV_STAGES", 0x3F);
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        n = 256;
+    t.cus = n;
+}
+Tuning& tuning() {
+    static Tuning t = [] { Tuning x; load_tuning(x); return x; }();  // thread-safe one-time initialisation
+    return t;
 }
 
 #define PV_LAUNCH_CHECK()                                   \
@@ -1183,12 +1231,13 @@ int launch_mask_bits(const VoteParams& P, hipStream_t s) {
     return 0;
 }
 
-int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
+int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mask = -1) {
     const bool literal = (P.flags & PVNET_F_LITERAL) != 0;
     auto mark = [&](int i) -> hipError_t { return ev ? hipEventRecord(ev[i], s) : hipSuccess; };
-    // development aid (tools/overlap_probe.py): bit i set = launch stage i (K1, K1b, K2, K3, K4, K5); a workspace
-    // left by a complete call stays valid, so single stages can be re-run on it in isolation
-    const int stages = env_int("PVNET_DEV_STAGES", 0x3F);
+    // bit i set = launch stage i (K1, K1b, K2, K3, K4, K5); a workspace left by a complete call stays valid, so single
+    // stages can be re-run on it in isolation (pvnet_vote_v3_stage_repeat; development aid: PVNET_DEV_STAGES)
+    const Tuning& T = tuning();
+    const int stages = stage_mask >= 0 ? stage_mask : T.dev_stages;
     PV_HIP(mark(0));
     {   // K1
         if (stages & 1) {
@@ -1207,7 +1256,7 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
         PV_HIP(mark(2));
     }
     if (stages & 4) {   // K2
-        const int kg = env_int("PVNET_COMPACT_KG", 3);
+        const int kg = T.compact_kg;
         dim3 grid(P.nseg, P.b, (P.vn + kg - 1) / kg);
         if (literal) hipLaunchKernelGGL((compact_kernel<true, 3>), dim3(P.nseg, P.b, (P.vn + 2) / 3), dim3(256), 0, s, P);
         else if (kg == 1) hipLaunchKernelGGL((compact_kernel<false, 1>), grid, dim3(256), 0, s, P);
@@ -1226,8 +1275,8 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev) {
     if (stages & 16) {   // K4: persistent grid, work items strided over its waves
         const long long max_items =
             (long long)P.b * P.vn * (P.hgroups / P.wg_g) * ((P.max_chunks + P.wg_s - 1) / P.wg_s);
-        const int wgs_per_cu = env_int("PVNET_SCORE_WGS_PER_CU", 8);
-        long long wgs = wgs_per_cu > 0 ? (long long)num_cus() * wgs_per_cu : max_items;  // 0: one workgroup per item
+        const int wgs_per_cu = T.wgs_per_cu;
+        long long wgs = wgs_per_cu > 0 ? (long long)T.cus * wgs_per_cu : max_items;  // 0: one workgroup per item
         if (wgs > max_items) wgs = max_items;
         if (wgs < 1) wgs = 1;
         if (!literal && P.mode) {
@@ -1280,6 +1329,7 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     P.words = L.words; P.cap = L.cap; P.chunk = L.chunk; P.max_chunks = L.max_chunks;
     P.hpl = L.hpl; P.hgroups = L.hgroups; P.hn_pad = L.hn_pad; P.wg_g = L.wg_g; P.wg_s = L.wg_s;
     P.mode = L.reserved_;
+    P.score_xcd = tuning().score_xcd;
     P.thresh = thresh;
     P.tau = (thresh > 0.f && thresh < 1.f) ? (float)(sqrt(1.0 - (double)thresh * thresh) / (double)thresh) : 0.f;
     P.min_num = min_num; P.max_num = max_num; P.seed = seed; P.image_base = image_base; P.idxs = idxs; P.flags = flags;
@@ -1309,6 +1359,7 @@ extern "C" {
 
 int pvnet_vote_abi_version(void) { return PVNET_VOTE_ABI_VERSION; }
 const char* pvnet_vote_build_info(void) { return "pvnet_vote gfx950 hip " __DATE__ " " __TIME__; }
+void pvnet_vote_tuning_reload(void) { load_tuning(tuning()); }
 
 int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVoteLayout* L) {
     if (!L || b <= 0 || h <= 0 || w <= 0 || vn <= 0 || hn <= 0 || max_num < 0) return PVNET_E_BADARG;
@@ -1321,9 +1372,10 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
         cap = c < npix ? c : npix;
     }
     cap = (cap + PAD - 1) / PAD * PAD + PAD;
-    const int mode = env_int("PVNET_SCORE_MODE", 1);  // 1: matrix-pipe scoring in fast mode, 0: VALU scoring
+    const Tuning& T = tuning();
+    const int mode = T.score_mode;  // 1: matrix-pipe scoring in fast mode, 0: VALU scoring
     int hpl = hn >= 768 ? 8 : (hn >= 384 ? 4 : (hn >= 128 || mode ? 2 : 1));  // tuned at hn = 1024 (profiles/r01_tune13)
-    hpl = env_int("PVNET_SCORE_HPL", hpl);
+    if (T.hpl >= 0) hpl = T.hpl;
     if (hpl != 1 && hpl != 2 && hpl != 4 && hpl != 8) return PVNET_E_UNSUPPORTED;
     if (mode && hpl == 1) return PVNET_E_UNSUPPORTED;  // a matrix-pipe work item holds >= 128 hypotheses
     int hgroups = (hn + 64 * hpl - 1) / (64 * hpl);
@@ -1333,7 +1385,7 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
 
     const long long units = (long long)b * vn * hgroups;
     int chunk = units >= 128 ? 128 : 64;
-    chunk = env_int("PVNET_SCORE_CHUNK", chunk);
+    if (T.chunk >= 0) chunk = T.chunk;
     if (chunk < PAD || chunk % PAD != 0 || chunk > 1024) return PVNET_E_UNSUPPORTED;  // LDS: 4 * 1024 * 32 B
     if (mode && chunk % 32 != 0) return PVNET_E_UNSUPPORTED;  // whole 32-pixel MFMA tiles
     // a matrix-pipe work item is (4 / wg_g) * chunk pixels; its wrapped vote accumulators hold 16 votes per 32-pixel tile
@@ -1435,6 +1487,39 @@ int pvnet_vote_v3_profiled(const void* mask, int mask_dtype, const int64_t mask_
     return rc;
 }
 
+int pvnet_vote_v3_stage_repeat(const void* mask, int mask_dtype, const int64_t mask_strides[3], const float* vertex,
+                               const int64_t vertex_strides[5], int b, int h, int w, int vn, int hn,
+                               float inlier_thresh, int min_num, int max_num, uint64_t seed, int image_base,
+                               const int32_t* idxs, uint32_t flags, float* out_kpts, int32_t* out_status,
+                               void* workspace, size_t workspace_bytes, void* stream, int stage, int repeats,
+                               float* avg_ms) {
+    if (!avg_ms || stage < 0 || stage >= PVNET_NUM_STAGES || repeats < 1) return PVNET_E_BADARG;
+    VoteParams P;
+    int rc = fill_params(P, mask, mask_dtype, mask_strides, vertex, vertex_strides, b, h, w, vn, hn, inlier_thresh,
+                         min_num, max_num, seed, image_base, idxs, flags, out_kpts, out_status, workspace,
+                         workspace_bytes);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipEvent_t ev[2];
+    if (hipEventCreate(&ev[0]) != hipSuccess) return (int)hipErrorOutOfMemory;
+    if (hipEventCreate(&ev[1]) != hipSuccess) { (void)hipEventDestroy(ev[0]); return (int)hipErrorOutOfMemory; }
+    rc = launch_all(P, s, nullptr, 0x3F);  // one complete pass: the workspace now holds what every stage consumes
+    if (rc == 0) rc = (int)hipEventRecord(ev[0], s);
+    for (int i = 0; rc == 0 && i < repeats; ++i) rc = launch_all(P, s, nullptr, 1 << stage);
+    if (rc == 0) rc = (int)hipEventRecord(ev[1], s);
+    hipError_t e = hipStreamSynchronize(s);
+    if (rc == 0 && e != hipSuccess) rc = (int)e;
+    if (rc == 0) {
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, ev[0], ev[1]);
+        if (e != hipSuccess) rc = (int)e;
+        *avg_ms = ms / (float)repeats;
+    }
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+    return rc;
+}
+
 static int params_for_workspace(VoteParams& P, int b, int h, int w, int vn, int hn, int max_num, void* ws,
                                 size_t ws_bytes) {
     static const int64_t ms[3] = {0, 0, 1}, vs[5] = {0, 0, 0, 0, 1};
@@ -1449,12 +1534,9 @@ int pvnet_vote_confidence(const float* kpts, float thresh, float* out_conf, uint
     VoteParams P;
     int rc = params_for_workspace(P, b, h, w, vn, hn, max_num, workspace, workspace_bytes);
     if (rc) return rc;
-    if (vote_flags & PVNET_F_LITERAL)  // the record format the preceding vote call left in the workspace
-        hipLaunchKernelGGL(confidence_kernel<true>, dim3(vn, b), dim3(256), 0, static_cast<hipStream_t>(stream), P,
-                           kpts, thresh, out_conf);
-    else
-        hipLaunchKernelGGL(confidence_kernel<false>, dim3(vn, b), dim3(256), 0, static_cast<hipStream_t>(stream), P,
-                           kpts, thresh, out_conf);
+    (void)vote_flags;  // records hold the raw direction in both scoring modes: nothing depends on the mode any more
+    hipLaunchKernelGGL(confidence_kernel, dim3(vn, b), dim3(256), 0, static_cast<hipStream_t>(stream), P, kpts, thresh,
+                       out_conf);
     PV_LAUNCH_CHECK();
     return 0;
 }

@@ -68,6 +68,8 @@ def load_library() -> C.CDLL:
     lib.pvnet_vote_v3_logits.argtypes = [f32p, i64p, C.c_int, f32p, i64p] + v3_args[5:]
     lib.pvnet_vote_v3_profiled.restype = C.c_int
     lib.pvnet_vote_v3_profiled.argtypes = v3_args + [C.POINTER(C.c_float)]
+    lib.pvnet_vote_v3_stage_repeat.restype = C.c_int
+    lib.pvnet_vote_v3_stage_repeat.argtypes = v3_args + [C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.pvnet_generate_hypothesis.restype = C.c_int
     lib.pvnet_generate_hypothesis.argtypes = [f32p, f32p, i32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.pvnet_voting_for_hypothesis.restype = C.c_int
@@ -83,10 +85,17 @@ def load_library() -> C.CDLL:
     lib.pvnet_vote_confidence.argtypes = [f32p, C.c_float, f32p, C.c_uint32] + ws_tail
     lib.pvnet_vote_distribution.restype = C.c_int
     lib.pvnet_vote_distribution.argtypes = [f32p, f32p] + ws_tail
-    if lib.pvnet_vote_abi_version() != 2:
+    lib.pvnet_vote_tuning_reload.restype = None
+    lib.pvnet_vote_tuning_reload.argtypes = []
+    if lib.pvnet_vote_abi_version() != 3:
         raise RuntimeError("pvnet_amd: libpvnet_vote.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib
+
+
+def reload_tuning():
+    """re-read the PVNET_* tuning environment variables (the library reads them once, at its first call)."""
+    load_library().pvnet_vote_tuning_reload()
 
 
 def _check(rc: int, what: str):
@@ -160,10 +169,39 @@ def _debug_views(ws: torch.Tensor, L: Layout):
     )
 
 
+def effective_literal(literal: bool, inlier_thresh: float) -> bool:
+    """the scoring mode a call really runs in: the sqrt-free fast predicate folds 1/thresh into the records and needs
+    0 < thresh < 1; outside that range the library scores literally (fill_params, pvnet_vote.hip) -- and then leaves
+    LITERAL-format records (x, y, ux, uy) in the workspace, which every consumer of that workspace must know."""
+    t = float(inlier_thresh)
+    return bool(literal) or not (0.0 < t < 1.0)
+
+
+def _workspace(workspace, L: Layout, dev) -> torch.Tensor:
+    if workspace is None:
+        return torch.empty(L.total_bytes, dtype=torch.uint8, device=dev)
+    if not (isinstance(workspace, torch.Tensor) and workspace.is_cuda and workspace.device == dev and
+            workspace.dtype == torch.uint8 and workspace.is_contiguous() and workspace.numel() >= L.total_bytes):
+        raise RuntimeError(f"workspace must be a contiguous uint8 CUDA tensor of >= {L.total_bytes} bytes on {dev}")
+    if workspace.data_ptr() % 256:
+        raise RuntimeError("workspace must be 256-byte aligned")
+    return workspace
+
+
+_RETURN_KW = ("return_status", "return_debug", "stage_times")
+
+
+def _strip_return_kw(kw: dict) -> dict:
+    """the sibling wrappers call v3 with return_debug=True themselves: a caller's return_* keyword would change the
+    shape of what comes back, so it is dropped here (their own return values are fixed by the reference)."""
+    return {k: v for k, v in kw.items() if k not in _RETURN_KW}
+
+
 def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99, max_iter=20,
                            min_num=5, max_num=30000, *, idxs: Optional[torch.Tensor] = None,
                            seed: Optional[int] = None, image_offset: int = 0, literal: bool = False, refine: bool = True,
-                           return_status: bool = False, return_debug: bool = False, stage_times: bool = False):
+                           return_status: bool = False, return_debug: bool = False, stage_times: bool = False,
+                           workspace: Optional[torch.Tensor] = None):
     """Drop-in for the reference's ``ransac_voting_layer_v3`` (ransac_voting_gpu.py:514-598).
 
     :param mask:      [b,h,w]  any integer / bool / float dtype; foreground <=> ``mask.byte() != 0``
@@ -185,16 +223,20 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
       refine  False skips the least-squares refinement (:579-595) and returns the winning hypotheses
       return_status / return_debug / stage_times: also return the per-(image,kp) status bits / typed views of
               the workspace / per-stage GPU milliseconds (synchronises; for bench.py)
+      workspace  a caller-owned uint8 CUDA tensor of >= ``vote_layout(...).total_bytes`` bytes to use instead of a
+              fresh allocation (the caller then guarantees that no other call in flight on another stream uses it);
+              ``VotePlan`` wraps this for repeated calls of one shape
     """
     lib = load_library()
     mask, vertex, b, h, w, vn, hn, max_num, idxs = _prepare(mask, vertex, round_hyp_num, max_num, idxs)
     dev = vertex.device
     if seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    literal = effective_literal(literal, inlier_thresh)
     flags = (F_LITERAL if literal else 0) | (0 if refine else F_NO_REFINE)
     L = vote_layout(b, h, w, vn, hn, max_num)
     with torch.cuda.device(dev):
-        ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=dev)
+        ws = _workspace(workspace, L, dev)
         out = torch.empty((b, vn, 2), dtype=torch.float32, device=dev)
         status = torch.empty((b, vn), dtype=torch.int32, device=dev) if (return_status or return_debug) else None
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -226,11 +268,76 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
     return (out, *extras) if extras else out
 
 
+def stage_repeat_ms(mask, vertex, round_hyp_num, inlier_thresh=0.999, min_num=5, max_num=30000, *, stage="score",
+                    repeats=200, seed=0, image_offset=0, literal=False) -> float:
+    """profiling: average GPU milliseconds of ONE stage (a name of STAGE_NAMES) re-launched ``repeats`` times back to
+    back after one complete pass (``pvnet_vote_v3_stage_repeat``); synchronises."""
+    lib = load_library()
+    mask, vertex, b, h, w, vn, hn, max_num, _ = _prepare(mask, vertex, round_hyp_num, max_num, None)
+    dev = vertex.device
+    flags = F_LITERAL if effective_literal(literal, inlier_thresh) else 0
+    L = vote_layout(b, h, w, vn, hn, max_num)
+    with torch.cuda.device(dev):
+        ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=dev)
+        out = torch.empty((b, vn, 2), dtype=torch.float32, device=dev)
+        ms = C.c_float(0.0)
+        _check(lib.pvnet_vote_v3_stage_repeat(
+            C.c_void_p(mask.data_ptr()), _MASK_CODES[mask.dtype], _strides(mask, 3), C.c_void_p(vertex.data_ptr()),
+            _strides(vertex, 5), b, h, w, vn, hn, C.c_float(inlier_thresh), int(min_num), max_num,
+            C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), int(image_offset), None, flags, C.c_void_p(out.data_ptr()), None,
+            C.c_void_p(ws.data_ptr()), C.c_size_t(L.total_bytes),
+            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), STAGE_NAMES.index(stage), int(repeats),
+            C.byref(ms)), "pvnet_vote_v3_stage_repeat")
+    return float(ms.value)
+
+
+class VotePlan:
+    """A voting call of ONE shape prepared once: layout, workspace, output tensor and the ctypes argument block are
+    built here, so a repeated call costs one ctypes call (six kernel launches) and nothing else on the host -- the
+    reference's real call sites vote one image at a time (tools/demo.py:55: hn 512; tools/train_linemod.py:106:
+    hn 128, max_num 100), where per-call host work is what the caller feels.
+
+        plan = VotePlan(mask, vertex, 512, inlier_thresh=0.99)     # example tensors fix shape / dtype / strides
+        kpts = plan(mask, vertex, seed=3)                          # [b, vn, 2]; valid until the next plan() call
+
+    The plan owns its workspace and its output: calls of one plan must be issued on one stream at a time, and the
+    returned tensor is overwritten by the next call (clone it to keep it)."""
+
+    def __init__(self, mask, vertex, round_hyp_num, inlier_thresh=0.999, min_num=5, max_num=30000, *, literal=False,
+                 refine=True):
+        self.lib = load_library()
+        mask, vertex, b, h, w, vn, hn, max_num, _ = _prepare(mask, vertex, round_hyp_num, max_num, None)
+        self.key = (mask.dtype, tuple(mask.shape), tuple(mask.stride()), vertex.dtype, tuple(vertex.shape),
+                    tuple(vertex.stride()), vertex.device)
+        self.dev = vertex.device
+        self.layout = vote_layout(b, h, w, vn, hn, max_num)
+        self.literal = effective_literal(literal, inlier_thresh)
+        flags = (F_LITERAL if self.literal else 0) | (0 if refine else F_NO_REFINE)
+        with torch.cuda.device(self.dev):
+            self.workspace = torch.empty(self.layout.total_bytes, dtype=torch.uint8, device=self.dev)
+            self.out = torch.empty((b, vn, 2), dtype=torch.float32, device=self.dev)
+        self._ms, self._vs = _strides(mask, 3), _strides(vertex, 5)
+        self._head = (_MASK_CODES[mask.dtype], self._ms)
+        self._mid = (self._vs, b, h, w, vn, hn, C.c_float(inlier_thresh), int(min_num), max_num)
+        self._tail = (None, flags, C.c_void_p(self.out.data_ptr()), None, C.c_void_p(self.workspace.data_ptr()),
+                      C.c_size_t(self.layout.total_bytes))
+
+    def __call__(self, mask, vertex, seed: int = 0, image_offset: int = 0) -> torch.Tensor:
+        if (mask.dtype, tuple(mask.shape), tuple(mask.stride()), vertex.dtype, tuple(vertex.shape),
+                tuple(vertex.stride()), vertex.device) != self.key:
+            raise RuntimeError("VotePlan: tensors differ in dtype / shape / strides / device from the planned call")
+        rc = self.lib.pvnet_vote_v3(mask.data_ptr(), *self._head, vertex.data_ptr(), *self._mid,
+                                    seed & 0xFFFFFFFFFFFFFFFF, image_offset, *self._tail,
+                                    torch.cuda.current_stream(self.dev).cuda_stream)
+        if rc:
+            _check(rc, "pvnet_vote_v3")
+        return self.out
+
+
 def debug_dir(dbg) -> torch.Tensor:
-    """raw directions [b,vn,cap,2] as the records of a ``return_debug`` result carry them: fast records are
-    (x, y, My, -Mx) with M = 2^90 * u (an exact scaling), literal records hold (x, y, ux, uy)."""
-    rec = dbg["rec"]
-    return rec[..., 2:4] if dbg["literal"] else torch.stack([-rec[..., 3], rec[..., 2]], -1) * 2.0 ** -90
+    """raw directions [b,vn,cap,2] as the records of a ``return_debug`` result carry them: (x, y, ux, uy) in both
+    scoring modes (fast mode stores a zero direction for |u| < 1e-6, which never votes)."""
+    return dbg["rec"][..., 2:4]
 
 
 def ransac_voting_layer_v3_from_logits(seg_pred, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99,
@@ -250,7 +357,7 @@ def ransac_voting_layer_v3_from_logits(seg_pred, vertex, round_hyp_num, inlier_t
     dev = vertex.device
     if seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-    flags = (F_LITERAL if literal else 0) | (0 if refine else F_NO_REFINE)
+    flags = (F_LITERAL if effective_literal(literal, inlier_thresh) else 0) | (0 if refine else F_NO_REFINE)
     L = vote_layout(b, h, w, vn, hn, max_num)
     with torch.cuda.device(dev):
         ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=dev)
@@ -296,7 +403,7 @@ def ransac_voting_layer_v5(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
     :return: ([b,vn,2], [b,vn]) float32"""
     max_num = int(min(max(int(max_num), 0), 2 ** 31 - 1))
     out, dbg = ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh, confidence, max_iter, min_num,
-                                      max_num, return_debug=True, **kw)
+                                      max_num, return_debug=True, **_strip_return_kw(kw))
     L, ws = dbg["layout"], dbg["workspace"]
     conf = torch.empty((L.b, L.vn), dtype=torch.float32, device=out.device)
     with torch.cuda.device(out.device):
@@ -317,7 +424,7 @@ def estimate_voting_distribution_with_mean(mask, vertex, mean, round_hyp_num=256
     hn = -(-int(min_hyp_num) // int(round_hyp_num)) * int(round_hyp_num)
     max_num = int(min(max(int(max_num), 0), 2 ** 31 - 1))
     _, dbg = ransac_voting_layer_v3(mask, vertex, hn, inlier_thresh, min_num=min_num, max_num=max_num, refine=False,
-                                    return_debug=True, **kw)
+                                    return_debug=True, **_strip_return_kw(kw))
     L, ws = dbg["layout"], dbg["workspace"]
     mean_c = mean.to(device=ws.device, dtype=torch.float32).contiguous()
     cov = torch.empty((L.b, L.vn, 2, 2), dtype=torch.float32, device=ws.device)
@@ -335,7 +442,7 @@ def generate_hypothesis_counts(mask, vertex, round_hyp_num, inlier_thresh=0.999,
     visualiser of tools/demo.py:120-134): all hypotheses and their inlier counts.
     :return: ([b,hn,vn,2] float32, [b,hn,vn] int64)   (skipped images: zeros)"""
     _, dbg = ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh, min_num=min_num, max_num=max_num,
-                                    refine=False, return_debug=True, **kw)
+                                    refine=False, return_debug=True, **_strip_return_kw(kw))
     return dbg["hyp"].permute(0, 2, 1, 3).contiguous(), dbg["counts"].permute(0, 2, 1).contiguous().long()
 
 

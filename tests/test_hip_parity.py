@@ -111,10 +111,15 @@ def test_fast_mode_against_oracle64():
     cnt = dbg["counts"].cpu().numpy().transpose(0, 2, 1)
     ref = np.stack([d["counts"] for d in d64])
     diff = np.abs(cnt - ref)
-    assert diff.max() <= 3 and (diff > 0).mean() < 0.02  # only threshold-edge pixels may flip (SURVEY hard part 2)
-    same = np.stack([d["win_idx"] for d in d64]) == dbg["win"][:, :, 0].cpu().numpy()
-    assert same.mean() > 0.9
-    assert np.abs(out.cpu().numpy() - o64)[same].max() < TOL_PX
+    assert diff.max() <= 2 and (diff > 0).mean() < 0.02  # only threshold-edge pixels may flip (SURVEY hard part 2)
+    win64 = np.stack([d["win_idx"] for d in d64])
+    winf = dbg["win"][:, :, 0].cpu().numpy()
+    flip = win64 != winf
+    if flip.any():  # a tie-break between hypotheses that exact arithmetic counts within 2 votes of each other
+        bi, ki = np.nonzero(flip)
+        assert np.abs(ref[bi, winf[bi, ki], ki] - ref[bi, win64[bi, ki], ki]).max() <= 2
+        assert np.abs(out.cpu().numpy() - o64)[flip].max() < 5e-2
+    assert np.abs(out.cpu().numpy() - o64)[~flip].max() < TOL_PX
 
 
 def test_clean_field_recovers_keypoints_any_rng():
@@ -265,8 +270,9 @@ def test_ops_reject_bad_inputs_like_check_input():
 # ------------------------------------------------------------------------------------------------ full size
 def test_baseline_size_batch_against_c_oracle():
     """BASELINE.json config 3 shapes (480x640, 9 kpts, 1024 hypotheses) on a batch of 4: literal mode must pick
-    the C oracle's winners exactly; the default fast mode must land within 1e-3 px wherever it agrees on the
-    winner, and that must be (almost) everywhere."""
+    the C oracle's winners exactly; the default fast mode counts every hypothesis within 2 votes of literal, lands
+    within 1e-3 px of the oracle, and may differ in a winner only as a tie-break between hypotheses whose literal
+    counts are within 2 votes (bounded and checked, never masked out)."""
     mask, planar, kpts = synth.make_batch(4, first_index=0, radius=40, noise=True, background="normal")
     vnp = synth.planar_to_vertex_view(planar)
     m, v = to_dev(mask, planar)
@@ -276,12 +282,19 @@ def test_baseline_size_batch_against_c_oracle():
     np.testing.assert_array_equal(dl["win"][:, :, 0].cpu().numpy(), wi)
     np.testing.assert_array_equal(dl["win"][:, :, 1].cpu().numpy(), wc)
     assert np.abs(lit.cpu().numpy() - ref).max() < 1e-4
+    counts_l = dl["counts"].clone()
     fast, df = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=20240, return_debug=True)
-    same = df["win"][:, :, 0].cpu().numpy() == wi
-    assert same.mean() >= 0.9
-    assert np.abs(fast.cpu().numpy() - ref)[same].max() < TOL_PX
-    dcnt = (df["counts"] - dl["counts"]).abs()
-    assert int(dcnt.max()) <= 4
+    dcnt = (df["counts"] - counts_l).abs()
+    assert int(dcnt.max()) <= 2
+    wf = df["win"][:, :, 0].cpu().numpy()
+    flip = wf != wi
+    if flip.any():  # only a tie-break between hypotheses the reference's arithmetic counts within 2 votes of each other
+        bi, ki = np.nonzero(flip)
+        cl = counts_l.cpu().numpy()
+        assert np.abs(cl[bi, ki, wf[bi, ki]] - cl[bi, ki, wi[bi, ki]]).max() <= 2
+        assert np.abs(fast.cpu().numpy() - ref)[flip].max() < 5e-2
+    assert np.abs(fast.cpu().numpy() - ref)[~flip].max() < TOL_PX
+    assert flip.sum() <= 1  # 36 key-points: the modes agree on (practically) every winner
 
 
 def test_baseline_size_properties_batch32():
@@ -527,8 +540,13 @@ def test_randomised_shapes_literal_vs_c_oracle(case):
     np.testing.assert_array_equal(dbg["win"][:, :, 1].cpu().numpy()[live], wc[live])
     good = np.isfinite(ref).all(-1) & (np.abs(ref) < 1e5).all(-1)  # near-singular fits can blow up on both sides
     assert np.abs(out.cpu().numpy() - ref)[good].max() < 2e-3 * max(1.0, np.abs(ref[good]).max() / 100)
-    fast = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, max_num=max_num, seed=seed)
+    counts_l = dbg["counts"].clone()
+    fast, df = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, max_num=max_num, seed=seed,
+                                             return_debug=True)
     assert torch.isfinite(fast).all()
+    # the default mode against the literal counts of the same draw: edge votes only (tests/test_fast_mode_parity.py
+    # holds the full set of fast-mode bars)
+    assert int((df["counts"] - counts_l).abs().max()) <= 2
 
 
 def test_concurrent_streams_reproduce_serial_results():
@@ -558,6 +576,7 @@ def test_concurrent_streams_reproduce_serial_results():
     {"PVNET_SCORE_CHUNK": "64"}, {"PVNET_SCORE_CHUNK": "256"},  # pixels per count row (2 and 8..16 tiles per item)
     {"PVNET_SCORE_HPL": "2"}, {"PVNET_SCORE_HPL": "4"},        # fewer hypotheses per work item (MH = 2, 4)
     {"PVNET_COMPACT_KG": "1"}, {"PVNET_COMPACT_KG": "9"},
+    {"PVNET_SCORE_XCD": "0"},                                  # work items strided over the grid, no XCD affinity
 ])
 def test_launch_knobs_do_not_change_results(knobs, monkeypatch):
     """Tuning knobs re-shape grids and work items, never results: literal mode stays bit-equal to
@@ -570,10 +589,21 @@ def test_launch_knobs_do_not_change_results(knobs, monkeypatch):
     ref_l, ref_f = ref_l.clone(), ref_f.clone()
     for k, x in knobs.items():
         monkeypatch.setenv(k, x)
-    out_l, d_l = voting.ransac_voting_layer_v3(m, v, 700, inlier_thresh=0.99, seed=9, literal=True, return_debug=True)
-    out_f, d_f = voting.ransac_voting_layer_v3(m, v, 700, inlier_thresh=0.99, seed=9, return_debug=True)
+    voting.reload_tuning()  # the library reads its knobs once; tests change them in-process
+    try:
+        out_l, d_l, out_f, d_f = _vote_both(m, v)
+    finally:
+        for k in knobs:
+            monkeypatch.delenv(k)
+        voting.reload_tuning()
     assert torch.equal(d_l["counts"], counts_l) and torch.equal(out_l, ref_l)
     assert torch.equal(d_f["counts"], counts_f) and torch.equal(out_f, ref_f)
+
+
+def _vote_both(m, v):
+    out_l, d_l = voting.ransac_voting_layer_v3(m, v, 700, inlier_thresh=0.99, seed=9, literal=True, return_debug=True)
+    out_f, d_f = voting.ransac_voting_layer_v3(m, v, 700, inlier_thresh=0.99, seed=9, return_debug=True)
+    return out_l, d_l, out_f, d_f
 
 
 

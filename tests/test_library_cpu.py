@@ -22,11 +22,12 @@ def test_exports_every_declared_symbol(lib):
     hdr = open(os.path.join(ROOT, "include", "pvnet_vote.h")).read()
     names = set(re.findall(r"\b(pvnet_[a-z0-9_]+)\s*\(", hdr))
     assert {"pvnet_vote_v3", "pvnet_vote_v3_profiled", "pvnet_generate_hypothesis", "pvnet_voting_for_hypothesis",
-            "pvnet_vote_workspace_bytes", "pvnet_vote_layout", "pvnet_vote_abi_version",
+            "pvnet_vote_workspace_bytes", "pvnet_vote_layout", "pvnet_vote_abi_version", "pvnet_vote_tuning_reload",
+            "pvnet_vote_v3_stage_repeat",
             "pvnet_vote_build_info"} <= names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/pvnet_vote.h but not exported"
-    assert lib.pvnet_vote_abi_version() == 2
+    assert lib.pvnet_vote_abi_version() == 3
     assert b"gfx950" in lib.pvnet_vote_build_info()
 
 
@@ -124,5 +125,32 @@ def test_oversized_matrix_pipe_items_are_refused(monkeypatch):
     """the wrapped vote accumulators of the matrix-pipe kernel hold < 512 votes: a work item of >= 1024 pixels is
     refused by pvnet_vote_layout instead of miscounting"""
     monkeypatch.setenv("PVNET_SCORE_CHUNK", "256")
-    with pytest.raises(RuntimeError, match="PVNET_E_UNSUPPORTED"):
-        voting.vote_layout(2, 120, 160, 9, 100, 30000)  # 100 hypotheses: 4 chunks per work item
+    voting.reload_tuning()  # knobs are read once, at the library's first call; re-read them explicitly
+    try:
+        with pytest.raises(RuntimeError, match="PVNET_E_UNSUPPORTED"):
+            voting.vote_layout(2, 120, 160, 9, 100, 30000)  # 100 hypotheses: 4 chunks per work item
+    finally:
+        monkeypatch.delenv("PVNET_SCORE_CHUNK")
+        voting.reload_tuning()
+    voting.vote_layout(2, 120, 160, 9, 100, 30000)  # and an environment change alone does nothing until reloaded
+
+
+def test_vote_epilogue_keeps_mfma_hazard_distance(tmp_path):
+    """vote8 reads MFMA results from inline asm, where LLVM inserts no XDL-write -> VALU-read wait states: the generated
+    assembly of every matrix-pipe scoring kernel is re-checked (tools/check_mfma_hazard.py), and the checker itself is
+    checked on a hand-made violation."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_mfma_hazard", os.path.join(ROOT, "tools", "check_mfma_hazard.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    assert chk.main([]) == 0  # compiles pvnet_vote.hip to assembly with the product's flags
+    bad = tmp_path / "bad.s"
+    bad.write_text("_Z17score_mfma_kernelILi9EEv:\n"
+                   "\tv_mfma_f32_32x32x16_bf16 v[2:17], v[144:147], v[82:85], 0\n"
+                   "\ts_nop 3\n"
+                   "\tv_sub_f32_e64 v50, v18, |v9| clamp\n"
+                   "\ts_endpgm\n.Lfunc_end0:\n")
+    assert chk.main([str(bad)]) == 1  # 4 wait states < 11
+    ok = tmp_path / "ok.s"
+    ok.write_text(bad.read_text().replace("s_nop 3", "s_nop 7\n\ts_nop 2"))
+    assert chk.main([str(ok)]) == 0  # 8 + 3 = 11

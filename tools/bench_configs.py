@@ -32,12 +32,43 @@ def run(name, b, radius, hn, thresh, max_num=30000, mask_dtype=torch.int64, step
           f"score {st['score'] * 1e3:7.1f} us  ({hn * 9 * tn * b / st['score'] / 1e9:6.2f} Tpairs/s)", flush=True)
 
 
+def run_plan(name, b, radius, hn, thresh, max_num=30000, steps=300):
+    """the same call through a prepared VotePlan (no per-call allocation / layout / argument marshalling): host cost of
+    a call = one ctypes call + six launches; and the GPU-side latency of ONE call on an idle stream (event pair)."""
+    mask, planar, _ = synth.make_batch(b, radius=radius, noise=True, background="normal")
+    m = torch.from_numpy(mask).to(dev)
+    v = synth.planar_to_vertex_view(torch.from_numpy(planar).to(dev))
+    plan = voting.VotePlan(m, v, hn, inlier_thresh=thresh, max_num=max_num)
+    for i in range(5):
+        plan(m, v, seed=i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        plan(m, v, seed=i)
+    t_issue = (time.perf_counter() - t0) / steps
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    lat = []
+    for i in range(30):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        plan(m, v, seed=i)
+        e1.record()
+        torch.cuda.synchronize()
+        lat.append(e0.elapsed_time(e1) * 1e3)
+    print(f"{name:44s} b={b:3d} hn={hn:5d} VotePlan: {dt * 1e6:8.1f} us/call back to back (host issue {t_issue * 1e6:6.1f} us), "
+          f"GPU latency of one call {np.median(lat):6.1f} us (min {min(lat):.1f})", flush=True)
+
+
 run("headline (cfg 3): R=40 int64", 32, 40, 1024, 0.99)
 run("uint8 mask", 32, 40, 1024, 0.99, mask_dtype=torch.uint8)
 run("thresh 0.999", 32, 40, 1024, 0.999)
 run("stress: R=97 (tn~29.5k)", 32, 97, 1024, 0.99)
 run("demo call site: b=1 hn=512", 1, 27, 512, 0.99)
 run("eval call site: b=1 hn=128 max_num=100", 1, 40, 128, 0.99, max_num=100)
+run_plan("demo call site: b=1 hn=512", 1, 27, 512, 0.99)
+run_plan("eval call site: b=1 hn=128 max_num=100", 1, 40, 128, 0.99, max_num=100)
 run("batch 8", 8, 40, 1024, 0.99)
 run("batch 128", 128, 40, 1024, 0.99, steps=10)
 run("literal mode (reference fp32 order)", 32, 40, 1024, 0.99, literal=True, steps=5)

@@ -42,6 +42,7 @@ elif os.environ.get("PROBE_SHORT"):
 print("library:", os.environ.get("PVNET_VOTE_LIB", "default"))
 for name, mask in CASES:
     os.environ["PVNET_DEV_STAGES"] = str(mask)
+    voting.reload_tuning()
     run(100)
     t0 = time.perf_counter()
     run(K)
@@ -49,4 +50,5 @@ for name, mask in CASES:
     print(f"{S} streams, {name:22s}: {dt * 1e3:.4f} ms per batch of 32", flush=True)
     if mask != 0x3F:  # restore valid workspaces
         os.environ["PVNET_DEV_STAGES"] = str(0x3F)
+        voting.reload_tuning()
         run(2 * S)

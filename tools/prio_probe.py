@@ -28,6 +28,7 @@ outs = [torch.empty((B, VN, 2), dtype=torch.float32, device=dev) for _ in range(
 def call(slot, i, stages, stream):
     m, v = sets[i % 2]
     os.environ["PVNET_DEV_STAGES"] = str(stages)
+    voting.reload_tuning()
     rc = lib.pvnet_vote_v3(C.c_void_p(m.data_ptr()), 3, voting._strides(m, 3), C.c_void_p(v.data_ptr()),
                            voting._strides(v, 5), B, H, W, VN, HN, C.c_float(0.99), 5, 30000, C.c_uint64(i), 0, None, 0,
                            C.c_void_p(outs[slot].data_ptr()), None, C.c_void_p(ws[slot].data_ptr()),

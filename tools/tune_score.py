@@ -43,6 +43,7 @@ for rnd in range(ROUNDS):  # interleaved rounds: run-to-run drift is a few perce
             os.environ.pop(k, None)
         for k, x in c.items():
             os.environ[k] = str(x)
+        voting.reload_tuning()
         res.setdefault(i, []).append(run())
 for i, c in enumerate(configs):
     ts = res[i]

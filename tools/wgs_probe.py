@@ -32,6 +32,7 @@ run(400)
 for rnd in range(2):
     for wgs in (os.environ.get("WGS_LIST", "3,4,6,8,12,0")).split(","):
         os.environ[os.environ.get("KNOB", "PVNET_SCORE_WGS_PER_CU")] = wgs
+        voting.reload_tuning()
         run(100)
         t0 = time.perf_counter()
         run(K)
