@@ -143,8 +143,11 @@ int pvnet_vote_v3_profiled(const void* mask, int mask_dtype, const int64_t mask_
 
 /* Profiling only, like pvnet_vote_v3_profiled: runs the whole path once, then re-launches ONE stage (PVNET_STAGE_*)
  * `repeats` times back to back on that workspace, bracketed by a single hipEvent pair on `stream`; synchronises.
- * *avg_ms (host) = elapsed / repeats: the stage's kernel duration as a kernel trace reports it (plus the ~1.5 us
- * dependent-launch boundary), free of host launch gaps and cold clocks.  bench.py's roofline uses it. */
+ * avg_ms (host, TWO floats): [1] = event time / repeats (kernel + the ~1.5 us dependent-launch boundary, at the clocks a
+ * back-to-back run sustains).  [0] = for PVNET_STAGE_SCORE in fast mode the kernel's own duration: a second series of
+ * `repeats` launches of the same kernel in which every workgroup stamps the constant-rate device clock at its first and
+ * last instruction (max end - min start per launch, averaged) -- what a kernel trace reports for it, measured live;
+ * for every other stage [0] = [1].  bench.py's roofline uses [0]. */
 int pvnet_vote_v3_stage_repeat(const void* mask, int mask_dtype, const int64_t mask_strides[3],
                                const float* vertex, const int64_t vertex_strides[5],
                                int b, int h, int w, int vn, int hn,

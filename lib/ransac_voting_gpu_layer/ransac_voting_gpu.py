@@ -46,7 +46,11 @@ def _load_upstream():
         if os.path.isfile(cand) and os.path.abspath(os.path.dirname(cand)) != here:
             spec = importlib.util.spec_from_file_location(__name__ + "_upstream", cand)
             mod = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(mod)  # its `import lib.ransac_voting_gpu_layer.ransac_voting` finds the HIP ops
+            wb, sys.dont_write_bytecode = sys.dont_write_bytecode, True  # no __pycache__ in somebody else's checkout
+            try:
+                spec.loader.exec_module(mod)
+            finally:
+                sys.dont_write_bytecode = wb  # its `import lib.ransac_voting_gpu_layer.ransac_voting` finds the HIP ops
             _upstream = mod
             return mod
     return None

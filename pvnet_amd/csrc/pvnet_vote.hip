@@ -745,8 +745,13 @@ __device__ __forceinline__ void vote8(unsigned& acc, float d0, float c0, float d
 constexpr int VOTE_WRAP = 512;  // vote8 accumulators hold their count mod 512
 __device__ __forceinline__ int votes_of(unsigned acc) { return (int)(((acc >> 23) * 383u) & 511u); }
 
-template <int MH>
+// TIMED (profiling entry pvnet_vote_v3_stage_repeat only): every workgroup stamps the constant-rate device clock at its
+// first and last instruction into the spare words of ctrl's global row (atomic min / max): max - min is the kernel's
+// duration as a kernel trace reports it, measured live and free of launch gaps.
+template <int MH, bool TIMED>
 __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
+    if (TIMED && threadIdx.x == 0)
+        atomicMin(reinterpret_cast<unsigned long long*>(P.ctrl + P.b * CTRL_STRIDE + 2), (unsigned long long)wall_clock64());
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* s_t = reinterpret_cast<uint4*>(smem);
     const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
@@ -829,6 +834,25 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
             if (half == 0) po[t * 32 + col] = (uint16_t)c;
         }
     }
+    if (TIMED) {
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicMax(reinterpret_cast<unsigned long long*>(P.ctrl + P.b * CTRL_STRIDE + 4), (unsigned long long)wall_clock64());
+    }
+}
+
+// profiling helpers of pvnet_vote_v3_stage_repeat: ctrl's global row holds {min start, max end, accumulated ticks}
+__global__ void ts_reset_kernel(int32_t* row, int clear_acc) {
+    unsigned long long* t = reinterpret_cast<unsigned long long*>(row + 2);
+    t[0] = ~0ull;
+    t[1] = 0ull;
+    if (clear_acc) t[2] = 0ull;
+}
+__global__ void ts_collect_kernel(int32_t* row) {
+    unsigned long long* t = reinterpret_cast<unsigned long long*>(row + 2);
+    if (t[1] > t[0]) t[2] += t[1] - t[0];
+    t[0] = ~0ull;
+    t[1] = 0ull;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1231,7 +1255,7 @@ int launch_mask_bits(const VoteParams& P, hipStream_t s) {
     return 0;
 }
 
-int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mask = -1) {
+int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mask = -1, bool timed_score = false) {
     const bool literal = (P.flags & PVNET_F_LITERAL) != 0;
     auto mark = [&](int i) -> hipError_t { return ev ? hipEventRecord(ev[i], s) : hipSuccess; };
     // bit i set = launch stage i (K1, K1b, K2, K3, K4, K5); a workspace left by a complete call stays valid, so single
@@ -1282,12 +1306,23 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
         if (!literal && P.mode) {
             const int mh = P.wg_g * P.hpl / 2;  // hypotheses per item = wg_g * 64 * hpl = 4 waves * mh * 32
             const size_t lds = (size_t)(P.wg_s * P.chunk / 32) * TILE_U4 * sizeof(uint4);
-            switch (mh) {
-                case 1: hipLaunchKernelGGL(score_mfma_kernel<1>, dim3((unsigned)wgs), dim3(256), lds, s, P); break;
-                case 2: hipLaunchKernelGGL(score_mfma_kernel<2>, dim3((unsigned)wgs), dim3(256), lds, s, P); break;
-                case 4: hipLaunchKernelGGL(score_mfma_kernel<4>, dim3((unsigned)wgs), dim3(256), lds, s, P); break;
-                case 8: hipLaunchKernelGGL(score_mfma_kernel<8>, dim3((unsigned)wgs), dim3(256), lds, s, P); break;
-                default: return PVNET_E_UNSUPPORTED;
+            const dim3 g((unsigned)wgs), t(256);
+            if (timed_score) {  // same code + two clock stamps per workgroup (pvnet_vote_v3_stage_repeat)
+                switch (mh) {
+                    case 1: hipLaunchKernelGGL((score_mfma_kernel<1, true>), g, t, lds, s, P); break;
+                    case 2: hipLaunchKernelGGL((score_mfma_kernel<2, true>), g, t, lds, s, P); break;
+                    case 4: hipLaunchKernelGGL((score_mfma_kernel<4, true>), g, t, lds, s, P); break;
+                    case 8: hipLaunchKernelGGL((score_mfma_kernel<8, true>), g, t, lds, s, P); break;
+                    default: return PVNET_E_UNSUPPORTED;
+                }
+            } else {
+                switch (mh) {
+                    case 1: hipLaunchKernelGGL((score_mfma_kernel<1, false>), g, t, lds, s, P); break;
+                    case 2: hipLaunchKernelGGL((score_mfma_kernel<2, false>), g, t, lds, s, P); break;
+                    case 4: hipLaunchKernelGGL((score_mfma_kernel<4, false>), g, t, lds, s, P); break;
+                    case 8: hipLaunchKernelGGL((score_mfma_kernel<8, false>), g, t, lds, s, P); break;
+                    default: return PVNET_E_UNSUPPORTED;
+                }
             }
         } else {
             int rc = literal ? launch_score<true>(P, dim3((unsigned)wgs), s) : launch_score<false>(P, dim3((unsigned)wgs), s);
@@ -1507,13 +1542,33 @@ int pvnet_vote_v3_stage_repeat(const void* mask, int mask_dtype, const int64_t m
     if (rc == 0) rc = (int)hipEventRecord(ev[0], s);
     for (int i = 0; rc == 0 && i < repeats; ++i) rc = launch_all(P, s, nullptr, 1 << stage);
     if (rc == 0) rc = (int)hipEventRecord(ev[1], s);
+    // the matrix-pipe scoring kernel once more, `repeats` times, stamping the device clock itself (fast mode only)
+    const bool device_clock = stage == PVNET_STAGE_SCORE && !(P.flags & PVNET_F_LITERAL) && P.mode;
+    int32_t* row = P.ctrl + P.b * CTRL_STRIDE;
+    if (rc == 0 && device_clock) {
+        hipLaunchKernelGGL(ts_reset_kernel, dim3(1), dim3(1), 0, s, row, 1);
+        for (int i = 0; rc == 0 && i < repeats; ++i) {
+            rc = launch_all(P, s, nullptr, 1 << stage, true);
+            hipLaunchKernelGGL(ts_collect_kernel, dim3(1), dim3(1), 0, s, row);
+        }
+        if (rc == 0) rc = (int)hipGetLastError();
+    }
     hipError_t e = hipStreamSynchronize(s);
     if (rc == 0 && e != hipSuccess) rc = (int)e;
     if (rc == 0) {
         float ms = 0.f;
         e = hipEventElapsedTime(&ms, ev[0], ev[1]);
         if (e != hipSuccess) rc = (int)e;
-        *avg_ms = ms / (float)repeats;
+        avg_ms[0] = avg_ms[1] = ms / (float)repeats;
+    }
+    if (rc == 0 && device_clock) {
+        unsigned long long ticks = 0;
+        int khz = 0, dev = 0;
+        e = hipMemcpy(&ticks, row + 6, sizeof(ticks), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev);
+        if (e != hipSuccess) rc = (int)e;
+        else if (khz > 0 && ticks > 0) avg_ms[0] = (float)((double)ticks / (double)khz / (double)repeats);
     }
     (void)hipEventDestroy(ev[0]);
     (void)hipEventDestroy(ev[1]);

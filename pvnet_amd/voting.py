@@ -269,9 +269,10 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
 
 
 def stage_repeat_ms(mask, vertex, round_hyp_num, inlier_thresh=0.999, min_num=5, max_num=30000, *, stage="score",
-                    repeats=200, seed=0, image_offset=0, literal=False) -> float:
-    """profiling: average GPU milliseconds of ONE stage (a name of STAGE_NAMES) re-launched ``repeats`` times back to
-    back after one complete pass (``pvnet_vote_v3_stage_repeat``); synchronises."""
+                    repeats=200, seed=0, image_offset=0, literal=False, both=False):
+    """profiling: average GPU milliseconds of ONE stage (a name of STAGE_NAMES) re-launched ``repeats`` times after one
+    complete pass (``pvnet_vote_v3_stage_repeat``); synchronises.  For the fast-mode scoring stage the value is the
+    kernel's own duration from device clock stamps; ``both=True`` also returns the back-to-back event average."""
     lib = load_library()
     mask, vertex, b, h, w, vn, hn, max_num, _ = _prepare(mask, vertex, round_hyp_num, max_num, None)
     dev = vertex.device
@@ -280,15 +281,15 @@ def stage_repeat_ms(mask, vertex, round_hyp_num, inlier_thresh=0.999, min_num=5,
     with torch.cuda.device(dev):
         ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=dev)
         out = torch.empty((b, vn, 2), dtype=torch.float32, device=dev)
-        ms = C.c_float(0.0)
+        ms = (C.c_float * 2)()
         _check(lib.pvnet_vote_v3_stage_repeat(
             C.c_void_p(mask.data_ptr()), _MASK_CODES[mask.dtype], _strides(mask, 3), C.c_void_p(vertex.data_ptr()),
             _strides(vertex, 5), b, h, w, vn, hn, C.c_float(inlier_thresh), int(min_num), max_num,
             C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), int(image_offset), None, flags, C.c_void_p(out.data_ptr()), None,
             C.c_void_p(ws.data_ptr()), C.c_size_t(L.total_bytes),
             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), STAGE_NAMES.index(stage), int(repeats),
-            C.byref(ms)), "pvnet_vote_v3_stage_repeat")
-    return float(ms.value)
+            ms), "pvnet_vote_v3_stage_repeat")
+    return (float(ms[0]), float(ms[1])) if both else float(ms[0])
 
 
 class VotePlan:

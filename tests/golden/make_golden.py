@@ -14,6 +14,10 @@ G6  ref_driver_v3.npz -- outputs of the REFERENCE'S OWN ransac_voting_layer_v3 (
 G7  ref_driver_siblings.npz -- the same for the reference's sibling functions of the "next" rows of SURVEY section 8(f):
                       ransac_voting_layer_v5 (:763-858), estimate_voting_distribution_with_mean (:333-406),
                       ransac_motion_voting (:960-981) and the Python-level generate_hypothesis (:983-1034).
+G8  reference_callers.json -- how the reference's OWN tools/demo.py and tools/train_linemod.py call the voting layer:
+                      both scripts imported UNCHANGED through tools/refshim.py (their five voting-layer imports bind this
+                      repository's HIP functions), every EvalWrapper's forward() run with recorders in place of the layer
+                      (tools/reference_callers_probe.py): function called, arguments, dtype / shape / strides of the tensors.
 G3  noisy_oracle.npz -- float64-oracle outputs (key-points, winner indices, winner counts) on seeded noisy
                       synthetic images with the counter-based RNG; guards the oracle itself against drift.
 """
@@ -155,8 +159,22 @@ def make_ref_siblings():
           "| cov[0,0]", cov[0, 0].round(4).tolist())
 
 
+def make_reference_callers():
+    import json
+    import subprocess
+    txt = subprocess.check_output([sys.executable, "-B", os.path.join(ROOT, "tools", "reference_callers_probe.py"), REF],
+                                  cwd="/tmp", stderr=subprocess.DEVNULL)
+    d = json.loads(txt)
+    d.pop("reference_root")
+    with open(os.path.join(OUT, "reference_callers.json"), "w") as f:
+        json.dump(d, f, indent=1, sort_keys=True)
+        f.write("\n")
+    print("wrote reference_callers.json:", list(d["calls"]))
+
+
 if __name__ == "__main__":
     if os.path.isdir(REF):
+        make_reference_callers()
         make_demo()
         make_ref_driver()
         make_ref_siblings()

@@ -54,21 +54,38 @@ def test_timed_mode_on_the_exact_bench_inputs():
 
 # ------------------------------------------------------------------------------------------------ (b) count bounds
 @pytest.mark.parametrize("thresh", [0.9, 0.99, 0.999])
-def test_fast_counts_within_two_votes_of_literal(thresh):
-    """inlier counts of the two modes on the same draw: <= 2 per hypothesis, <= 2e-6 of the pair tests in total (the
-    reference's own float32 test is the noisier side: 5.7e-7 of its decisions differ from exact arithmetic)"""
+def test_fast_counts_against_exact_arithmetic_and_literal(thresh):
+    """inlier counts of one draw in three arithmetics: float64 (oracle64, exact for this purpose), the reference's
+    float32 order (literal mode) and the timed fast mode.  Bars: fast vs float64 <= 2 per hypothesis and <= 2e-6 of the
+    pair tests; fast never farther from float64 than the reference's own arithmetic is (whose cos-based float32 test
+    loses resolution as thresh -> 1: ~6e-7 of its decisions differ from exact at 0.99, several e-6 at 0.999); fast vs
+    literal <= 2 per hypothesis."""
     mask, planar, _ = synth.make_batch(4, first_index=3000, h=240, w=320, radius=22, noise=True, background="normal")
+    vnp = synth.planar_to_vertex_view(planar)
     m, v = to_dev(mask, planar)
     hn = 512
     _, dl = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, seed=31, literal=True, return_debug=True)
-    cl = dl["counts"].clone()
-    tn = int(dl["tn"].sum())
+    cl, hyp = dl["counts"].clone(), dl["hyp"].clone()
     _, df = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, seed=31, return_debug=True)
-    d = (df["counts"] - cl).abs()
-    tests = hn * 9 * tn
-    assert int(d.max()) <= 2
-    assert int(d.sum()) <= max(2, 2e-6 * tests), (int(d.sum()), tests)
-    assert torch.equal(df["hyp"], dl["hyp"])  # hypothesis generation is the literal order in both modes
+    assert torch.equal(df["hyp"], hyp)  # hypothesis generation is the literal order in both modes
+    cf = df["counts"].cpu().numpy()
+    cl = cl.cpu().numpy()
+    hyp = hyp.cpu().numpy()
+    tests = err_f = err_l = 0
+    for bi in range(4):
+        coords, direct = O.compact(O.foreground(mask[bi]), vnp[bi])
+        c64 = O.voting_counts(direct, coords, hyp[bi].transpose(1, 0, 2).astype(np.float64), thresh, np.float64)  # [hn,vn]
+        tests += hn * 9 * coords.shape[0]
+        df_ = np.abs(cf[bi].T - c64)
+        dl_ = np.abs(cl[bi].T - c64)
+        assert df_.max() <= 2
+        err_f += int(df_.sum())
+        err_l += int(dl_.sum())
+    print(f"thresh {thresh}: {tests} pair tests; decisions differing from float64: fast {err_f} ({err_f / tests:.1e}), "
+          f"literal (reference order) {err_l} ({err_l / tests:.1e})")
+    assert err_f <= max(2, 2e-6 * tests), (err_f, tests)
+    assert err_f <= err_l + 2
+    assert int(np.abs(cf - cl).max()) <= 2
 
 
 @pytest.mark.parametrize("case", range(12))
@@ -94,7 +111,7 @@ def test_randomised_shapes_fast_vs_literal_counts(case):
                                              return_debug=True)
     d = (df["counts"] - cl).abs()
     assert int(d.max()) <= 2
-    assert int(d.sum()) <= max(2, 4e-6 * hn * vn * tn)
+    assert int(d.sum()) <= max(3, 2e-5 * hn * vn * tn)  # literal = the reference's own float32 noise (see above)
     same = (df["win"][:, :, 0] == wl[:, :, 0])
     # where the winner is the same hypothesis the refined points agree to the tolerance (same inliers up to edge votes)
     good = torch.isfinite(lit).all(-1) & (lit.abs() < 1e5).all(-1) & same

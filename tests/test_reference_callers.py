@@ -1,0 +1,137 @@
+"""Row N1: the reference's OWN callers -- tools/demo.py:46-55 and tools/train_linemod.py:94-131 -- run
+UNCHANGED on top of the HIP voting layer.
+
+* CPU, build container (has /root/reference, no GPU): both scripts are imported byte for byte through the launcher's
+  shims (tools/refshim.py); the five voting-layer names they import are checked to BE this repository's functions, and
+  the way every wrapper's forward() calls them (function, arguments, tensor dtype / shape / strides) must equal the
+  committed fixture G8 (tests/golden/reference_callers.json, made by the same probe).
+* GPU: where the reference checkout exists next to a GPU the wrappers are executed for real on the demo fixture's
+  ground-truth field; on the GPU box (no /root/reference) the recorded calls of G8 are replayed on the HIP layer --
+  same functions, same arguments, tensors built by the very permute / view the wrappers apply -- and the key-points
+  must be the fixture's analytic projections (G1), the pose the fixture's pose.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+FIXTURE = os.path.join(ROOT, "tests", "golden", "reference_callers.json")
+PROBE = os.path.join(ROOT, "tools", "reference_callers_probe.py")
+TOL_PX = 1e-3
+
+
+def _probe(*extra):
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    txt = subprocess.check_output([sys.executable, "-B", PROBE, REF, *extra], cwd="/tmp", env=env,
+                                  stderr=subprocess.DEVNULL, timeout=600)
+    return json.loads(txt)
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "tools")), reason="needs the reference checkout (build container)")
+def test_reference_scripts_import_unchanged_and_call_the_hip_layer_as_recorded():
+    got = _probe()
+    want = json.load(open(FIXTURE))
+    assert all(got["bound_to_hip_layer"].values()), got["bound_to_hip_layer"]  # `is` identity with pvnet_amd.voting.*
+    assert got["calls"] == want["calls"]
+    assert got["input"] == want["input"]
+    # the call sites of the reference, spelled out (tools/demo.py:55, tools/train_linemod.py:104-106,117,129-130)
+    c = want["calls"]
+    assert c["demo.EvalWrapper"]["calls"][0]["args"] == [512] and \
+        c["demo.EvalWrapper"]["calls"][0]["kwargs"] == {"inlier_thresh": 0.99}
+    assert c["train.EvalWrapper"]["calls"][0]["kwargs"] == {"inlier_thresh": 0.99, "max_num": 100}
+    assert c["train.EvalWrapper[use_uncertainty]"]["calls"][0]["function"] == "ransac_voting_layer_v5"
+    assert [x["function"] for x in c["train.UncertaintyEvalWrapper"]["calls"]] == \
+        ["ransac_voting_layer_v3", "estimate_voting_distribution_with_mean"]
+    assert c["train.MotionEvalWrapper"]["calls"][0]["function"] == "ransac_motion_voting"
+    mask_spec, vertex_spec = c["demo.EvalWrapper"]["calls"][0]["tensor_args"]
+    assert mask_spec["dtype"] == "torch.int64" and not vertex_spec["contiguous"]  # argmax mask, permuted planar view
+
+
+def test_probe_leaves_the_reference_tree_clean():
+    """importing from the reference checkout must never write into it (no __pycache__)"""
+    if not os.path.isdir(REF):
+        pytest.skip("no reference checkout")
+    import time
+    t0 = time.time()
+    _probe()
+    fresh = []
+    for d, _, fs in os.walk(REF):
+        fresh += [os.path.join(d, f) for f in fs if f.endswith(".pyc") and os.path.getmtime(os.path.join(d, f)) >= t0 - 1]
+    assert not fresh, fresh
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+def _demo_inputs(demo_fixture, dev):
+    from pvnet_amd import synth
+    mask = demo_fixture["mask"]
+    planar = synth.field_from_keypoints(mask.astype(bool), demo_fixture["points_2d"])
+    m = torch.from_numpy(mask.astype(np.int64)).to(dev)
+    seg_pred = torch.stack([1.0 - m.float(), m.float()])[None].contiguous()  # logits whose arg-max is the mask
+    vertex_pred = torch.from_numpy(planar[None]).to(dev)                       # [1, 2vn, h, w] as the backbone emits it
+    return seg_pred, vertex_pred
+
+
+def _as_the_wrappers_do(seg_pred, vertex_pred):
+    """the tensor preparation every EvalWrapper.forward of the reference performs (tools/demo.py:48-52)"""
+    vertex_pred = vertex_pred.permute(0, 2, 3, 1)
+    b, h, w, vn_2 = vertex_pred.shape
+    return torch.argmax(seg_pred, 1), vertex_pred.view(b, h, w, vn_2 // 2, 2)
+
+
+@pytest.mark.gpu
+def test_reference_wrappers_on_the_hip_layer(demo_fixture):
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    dev = torch.device("cuda:0")
+    from pvnet_amd import pnp as P
+    from pvnet_amd import voting
+    pts = demo_fixture["points_2d"]
+    if os.path.isdir(os.path.join(REF, "tools")):  # a GPU next to the reference checkout: the real thing
+        r = _probe("--device", "cuda")
+        outs = {k: [np.asarray(o) for o in v["outputs"]] for k, v in r["calls"].items()}
+    else:  # GPU box: replay what the unchanged scripts were recorded to do (fixture G8)
+        spec = json.load(open(FIXTURE))["calls"]
+        seg_pred, vertex_pred = _demo_inputs(demo_fixture, dev)
+        mask, vertex = _as_the_wrappers_do(seg_pred, vertex_pred)
+        b, h, w, vn, _ = vertex.shape
+        outs = {}
+        for label, rec in spec.items():
+            torch.manual_seed(7)
+            result = None
+            for call in rec["calls"]:
+                m_spec, v_spec = call["tensor_args"][:2]
+                # the tensors handed over are of the recorded kind: int64 arg-max mask, strided [b,h,w,vn,2] view
+                assert str(mask.dtype) == m_spec["dtype"] and mask.is_contiguous() == m_spec["contiguous"]
+                assert str(vertex.dtype) == v_spec["dtype"] and vertex.is_contiguous() == v_spec["contiguous"]
+                assert tuple(vertex.stride()) == (2 * vn * h * w, w, 1, 2 * h * w, h * w)
+                assert np.argsort(v_spec["stride"]).tolist() == np.argsort(list(vertex.stride())).tolist()
+                fn = getattr(voting, call["function"])
+                args = [mask, vertex]
+                if call["function"] == "estimate_voting_distribution_with_mean":
+                    args.append(result)  # the mean of the preceding v3 call (train_linemod.py:129-130)
+                result = fn(*args, *call["args"], **call["kwargs"])
+            r = result if isinstance(result, tuple) else (result,)
+            outs[label] = [x.detach().cpu().numpy() for x in r]
+    # demo.py:55 / train_linemod.py:106: key-points of the ground-truth field = the analytic projections
+    for label in ("demo.EvalWrapper", "train.EvalWrapper"):
+        kp = outs[label][0]
+        assert kp.shape == (1, 9, 2) and np.abs(kp[0] - pts).max() < (TOL_PX if label == "demo.EvalWrapper" else 5e-2)
+    # train_linemod.py:104: v5 = key-points + per-key-point confidence (clean field: every kept pixel agrees)
+    kp5, conf = outs["train.EvalWrapper[use_uncertainty]"]
+    assert kp5.shape == (1, 9, 2) and conf.shape == (1, 9) and np.abs(kp5[0] - pts).max() < 5e-2 and conf.min() > 0.9
+    # train_linemod.py:117: mean over the foreground of (vertex + pixel): a unit-vector field gives points near the object
+    mo = outs["train.MotionEvalWrapper"][0]
+    assert mo.shape == (1, 9, 2) and np.isfinite(mo).all()
+    # train_linemod.py:129-130: v3 mean + hypothesis covariance (clean field: hypotheses collapse onto the key-point)
+    mean, var = outs["train.UncertaintyEvalWrapper"]
+    assert mean.shape == (1, 9, 2) and var.shape == (1, 9, 2, 2) and np.abs(mean[0] - pts).max() < TOL_PX
+    assert np.isfinite(var).all() and np.abs(var).max() < 1.0
+    # and the pose the demo goes on to compute from these key-points (demo.py:166-171) is the fixture's
+    pose = P.pnp(demo_fixture["points_3d"], outs["demo.EvalWrapper"][0][0].astype(np.float64), demo_fixture["K"])
+    tr_cm, rot_deg = P.cm_degree_error(pose, demo_fixture["pose"].astype(np.float64))
+    assert tr_cm < 0.05 and rot_deg < 0.1
