@@ -13,8 +13,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", "pvnet_vote.hip")]
-DEPS = SRC + [os.path.join(HERE, "csrc", "pvnet_rng.h"), os.path.join(ROOT, "include", "pvnet_vote.h")]
+SRC = [os.path.join(HERE, "csrc", "pvnet_vote.hip"), os.path.join(HERE, "csrc", "pvnet_nn.hip")]
+DEPS = SRC + [os.path.join(HERE, "csrc", "pvnet_rng.h"), os.path.join(ROOT, "include", "pvnet_vote.h"),
+              os.path.join(ROOT, "include", "pvnet_nn.h")]
 LIB = os.path.join(HERE, "libpvnet_vote.so")
 ARCH = "gfx950"
 # host-side pose refinement (plain C++, g++): include/pvnet_pnp.h

@@ -745,13 +745,14 @@ __device__ __forceinline__ void vote8(unsigned& acc, float d0, float c0, float d
 constexpr int VOTE_WRAP = 512;  // vote8 accumulators hold their count mod 512
 __device__ __forceinline__ int votes_of(unsigned acc) { return (int)(((acc >> 23) * 383u) & 511u); }
 
-// TIMED (profiling entry pvnet_vote_v3_stage_repeat only): every workgroup stamps the constant-rate device clock at its
-// first and last instruction into the spare words of ctrl's global row (atomic min / max): max - min is the kernel's
-// duration as a kernel trace reports it, measured live and free of launch gaps.
+// TIMED (profiling entry pvnet_vote_v3_stage_repeat only): every workgroup stores the constant-rate device clock at its
+// first and last instruction into its own slot of the (idle during this stage) `counts` buffer -- two plain 8-byte
+// stores per workgroup; max end - min start over the slots is the kernel's duration as a kernel trace reports it,
+// measured live and free of launch gaps.
 template <int MH, bool TIMED>
 __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
-    if (TIMED && threadIdx.x == 0)
-        atomicMin(reinterpret_cast<unsigned long long*>(P.ctrl + P.b * CTRL_STRIDE + 2), (unsigned long long)wall_clock64());
+    unsigned long long* __restrict__ stamps = reinterpret_cast<unsigned long long*>(P.counts);
+    if (TIMED && threadIdx.x == 0) stamps[2 * blockIdx.x] = (unsigned long long)wall_clock64();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* s_t = reinterpret_cast<uint4*>(smem);
     const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
@@ -836,23 +837,31 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
     }
     if (TIMED) {
         __syncthreads();
-        if (threadIdx.x == 0)
-            atomicMax(reinterpret_cast<unsigned long long*>(P.ctrl + P.b * CTRL_STRIDE + 4), (unsigned long long)wall_clock64());
+        if (threadIdx.x == 0) stamps[2 * blockIdx.x + 1] = (unsigned long long)wall_clock64();
     }
 }
 
-// profiling helpers of pvnet_vote_v3_stage_repeat: ctrl's global row holds {min start, max end, accumulated ticks}
-__global__ void ts_reset_kernel(int32_t* row, int clear_acc) {
-    unsigned long long* t = reinterpret_cast<unsigned long long*>(row + 2);
-    t[0] = ~0ull;
-    t[1] = 0ull;
-    if (clear_acc) t[2] = 0ull;
-}
-__global__ void ts_collect_kernel(int32_t* row) {
-    unsigned long long* t = reinterpret_cast<unsigned long long*>(row + 2);
-    if (t[1] > t[0]) t[2] += t[1] - t[0];
-    t[0] = ~0ull;
-    t[1] = 0ull;
+// profiling helper of pvnet_vote_v3_stage_repeat: acc[0] += (max end - min start) over the n workgroup slots
+__global__ __launch_bounds__(256) void ts_collect_kernel(const unsigned long long* __restrict__ stamps, int n,
+                                                         unsigned long long* __restrict__ acc, int clear) {
+    unsigned long long lo = ~0ull, hi = 0ull;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const unsigned long long a = stamps[2 * i], b = stamps[2 * i + 1];
+        lo = a < lo ? a : lo;
+        hi = b > hi ? b : hi;
+    }
+    __shared__ unsigned long long s_lo[256], s_hi[256];
+    s_lo[threadIdx.x] = lo;
+    s_hi[threadIdx.x] = hi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 256; ++i) {
+            lo = s_lo[i] < lo ? s_lo[i] : lo;
+            hi = s_hi[i] > hi ? s_hi[i] : hi;
+        }
+        const unsigned long long prev = clear ? 0ull : acc[0];
+        acc[0] = prev + (hi > lo ? hi - lo : 0ull);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1255,7 +1264,8 @@ int launch_mask_bits(const VoteParams& P, hipStream_t s) {
     return 0;
 }
 
-int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mask = -1, bool timed_score = false) {
+int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mask = -1, bool timed_score = false,
+               int* score_grid = nullptr) {
     const bool literal = (P.flags & PVNET_F_LITERAL) != 0;
     auto mark = [&](int i) -> hipError_t { return ev ? hipEventRecord(ev[i], s) : hipSuccess; };
     // bit i set = launch stage i (K1, K1b, K2, K3, K4, K5); a workspace left by a complete call stays valid, so single
@@ -1303,6 +1313,7 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
         long long wgs = wgs_per_cu > 0 ? (long long)T.cus * wgs_per_cu : max_items;  // 0: one workgroup per item
         if (wgs > max_items) wgs = max_items;
         if (wgs < 1) wgs = 1;
+        if (score_grid) *score_grid = (int)wgs;
         if (!literal && P.mode) {
             const int mh = P.wg_g * P.hpl / 2;  // hypotheses per item = wg_g * 64 * hpl = 4 waves * mh * 32
             const size_t lds = (size_t)(P.wg_s * P.chunk / 32) * TILE_U4 * sizeof(uint4);
@@ -1544,12 +1555,16 @@ int pvnet_vote_v3_stage_repeat(const void* mask, int mask_dtype, const int64_t m
     if (rc == 0) rc = (int)hipEventRecord(ev[1], s);
     // the matrix-pipe scoring kernel once more, `repeats` times, stamping the device clock itself (fast mode only)
     const bool device_clock = stage == PVNET_STAGE_SCORE && !(P.flags & PVNET_F_LITERAL) && P.mode;
-    int32_t* row = P.ctrl + P.b * CTRL_STRIDE;
+    // ticks accumulate in the spare words of ctrl's global row; the stamps live in `counts` (rewritten by K5 anyway)
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(P.ctrl + P.b * CTRL_STRIDE + 2);
     if (rc == 0 && device_clock) {
-        hipLaunchKernelGGL(ts_reset_kernel, dim3(1), dim3(1), 0, s, row, 1);
         for (int i = 0; rc == 0 && i < repeats; ++i) {
-            rc = launch_all(P, s, nullptr, 1 << stage, true);
-            hipLaunchKernelGGL(ts_collect_kernel, dim3(1), dim3(1), 0, s, row);
+            int grid = 0;
+            rc = launch_all(P, s, nullptr, 1 << stage, true, &grid);
+            if ((size_t)grid * 16 > sizeof(int32_t) * (size_t)P.b * P.vn * P.hn_pad) rc = PVNET_E_UNSUPPORTED;
+            if (rc == 0)
+                hipLaunchKernelGGL(ts_collect_kernel, dim3(1), dim3(256), 0, s,
+                                   reinterpret_cast<const unsigned long long*>(P.counts), grid, acc, i == 0 ? 1 : 0);
         }
         if (rc == 0) rc = (int)hipGetLastError();
     }
@@ -1564,7 +1579,7 @@ int pvnet_vote_v3_stage_repeat(const void* mask, int mask_dtype, const int64_t m
     if (rc == 0 && device_clock) {
         unsigned long long ticks = 0;
         int khz = 0, dev = 0;
-        e = hipMemcpy(&ticks, row + 6, sizeof(ticks), hipMemcpyDeviceToHost);
+        e = hipMemcpy(&ticks, acc, sizeof(ticks), hipMemcpyDeviceToHost);
         if (e == hipSuccess) e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev);
         if (e != hipSuccess) rc = (int)e;

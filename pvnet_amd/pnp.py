@@ -204,11 +204,21 @@ def pnp_batch(points_3d, points_2d, camera_matrix, weights_2d=None):
 
 
 # ---- metrics of Evaluator (evaluation_utils.py:75-134) -----------------------------------------------------
-def projection_2d_error(pose_pred, pose_target, model, K):
+def projection_2d_error(pose_pred, pose_target, model, K, symmetric=False):
+    """mean 2-D distance of the projected model points (:75-82); symmetric=True pairs every target point with the
+    NEAREST predicted one (projection_2d_sym, :84-91; GPU nearest-neighbour search, pvnet_amd/evaluation.py)"""
+    if symmetric:
+        from . import evaluation
+        return evaluation.projection_2d_error(pose_pred, pose_target, model, K, symmetric=True)
     return float(np.mean(np.linalg.norm(project(model, pose_pred, K) - project(model, pose_target, K), axis=-1)))
 
 
-def add_error(pose_pred, pose_target, model):
+def add_error(pose_pred, pose_target, model, symmetric=False):
+    """ADD (:95-109); symmetric=True is ADD-S (add_metric_sym, :111-122): nearest-neighbour distances, for the
+    symmetric classes (eggbox, glue)"""
+    if symmetric:
+        from . import evaluation
+        return evaluation.add_error(pose_pred, pose_target, model, symmetric=True)
     a = model @ pose_pred[:, :3].T + pose_pred[:, 3]
     b = model @ pose_target[:, :3].T + pose_target[:, 3]
     return float(np.mean(np.linalg.norm(a - b, axis=-1)))

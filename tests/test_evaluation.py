@@ -1,0 +1,155 @@
+"""Pose evaluation (remainder): the GPU nearest-neighbour search behind ADD-S and the Evaluator
+aggregator, against the numpy oracle of nearest_neighborhood.cu:48-117 (oracle/nn_oracle.py) and scipy's cKDTree."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+from scipy.spatial import cKDTree
+
+from oracle import nn_oracle
+from pvnet_amd import evaluation as E
+from pvnet_amd import pnp as P
+from pvnet_amd import voting
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def clouds(pn1, pn2, dim, seed, dup=0):
+    rng = np.random.default_rng(seed)
+    ref = rng.uniform(-0.1, 0.1, (pn1, dim)).astype(np.float32)
+    que = rng.uniform(-0.1, 0.1, (pn2, dim)).astype(np.float32)
+    if dup:  # exact ties: duplicated reference points (the first copy must win) and queries sitting on references
+        ref[pn1 // 2: pn1 // 2 + dup] = ref[:dup]
+        que[:dup] = ref[:dup]
+    return ref, que
+
+
+# ------------------------------------------------------------------------------------------------------------ CPU
+@pytest.mark.parametrize("dim", [2, 3])
+def test_oracle_against_kdtree_and_tie_break(dim):
+    ref, que = clouds(700, 500, dim, 1, dup=20)
+    idx = nn_oracle.find_nearest_point_idx(ref, que)
+    d_or = np.linalg.norm(ref[idx].astype(np.float64) - que, axis=1)
+    d_kd, _ = cKDTree(ref.astype(np.float64)).query(que.astype(np.float64))
+    np.testing.assert_allclose(d_or, d_kd, rtol=1e-5, atol=1e-7)  # same distances (indices may differ only in ties)
+    assert (idx[:20] == np.arange(20)).all()  # duplicated points: the FIRST copy wins (strict `<` scan from index 0)
+    ex = nn_oracle.find_nearest_point_idx(ref, ref, exclude_self=True)
+    assert (ex != np.arange(700)).all()
+    assert (ex[:20] == 350 + np.arange(20)).all() and (ex[350:370] == np.arange(20)).all()  # each other's twins
+    assert nn_oracle.find_nearest_point_idx(np.zeros((0, dim), np.float32), que).tolist() == [0] * 500
+
+
+def test_header_symbols_are_exported():
+    lib = voting.load_library()
+    hdr = open(os.path.join(ROOT, "include", "pvnet_nn.h")).read()
+    names = set(re.findall(r"\b(pvnet_[a-z0-9_]+|findNearestPointIdxLauncher)\s*\(", hdr))
+    assert names == {"pvnet_nearest_workspace_bytes", "pvnet_nearest_point_idx", "findNearestPointIdxLauncher"}
+    for n in names:
+        assert hasattr(lib, n), n
+    lib.pvnet_nearest_workspace_bytes.restype = C.c_size_t
+    assert lib.pvnet_nearest_workspace_bytes(2, 1000) == 16128 and lib.pvnet_nearest_workspace_bytes(0, 5) == 0
+    lib.pvnet_nearest_point_idx.restype = C.c_int
+    assert lib.pvnet_nearest_point_idx(None, None, None, 1, 1, 1, 3, 0, None, 0, None) == -1  # PVNET_E_BADARG
+
+
+def _toy_object(seed=0, n=400):
+    rng = np.random.default_rng(seed)
+    model = rng.uniform(-0.05, 0.05, (n, 3))
+    kp3d = np.concatenate([rng.uniform(-0.05, 0.05, (8, 3)), np.zeros((1, 3))])
+    pose = np.concatenate([P.rodrigues(np.array([0.2, -0.4, 0.1])), np.array([[0.03], [-0.02], [0.8]])], 1)
+    return model, kp3d, pose
+
+
+def test_evaluator_asymmetric_metrics_and_aggregation():
+    model, kp3d, pose = _toy_object()
+    diameter = float(np.max(np.linalg.norm(model[:, None] - model[None], axis=-1)))
+    ev = E.Evaluator(models={"cat": model}, diameters={"cat": diameter}, points_3d={"cat": kp3d})
+    pts2d = P.project(kp3d, pose, P.LINEMOD_K)
+    p = ev.evaluate(pts2d, pose, "cat")  # exact key-points: the pose comes back, every metric passes
+    assert P.cm_degree_error(p, pose)[0] < 1e-3
+    off = pose.copy()
+    off[:, 3] += [0.0, 0.0, 0.2]  # 20 cm along the optical axis: ADD and 5cm/5deg fail, 2-D projection shrinks
+    ev.evaluate(P.project(kp3d, off, P.LINEMOD_K), pose, "cat")
+    assert ev.add_recorder == [True, False] and ev.cm_degree_5_recorder == [True, False]
+    assert ev.projection_2d_recorder[0] is True or ev.projection_2d_recorder[0] == True  # noqa: E712
+    assert abs(ev.add_dists[1] - 0.2) < 1e-3 and ev.add_dists[0] < 1e-4
+    proj, add, cm = ev.average_precision(verbose=False)
+    assert add == 0.5 and cm == 0.5 and proj in (0.5, 1.0)
+    # the uncertainty paths run on the same recorders (isotropic covariances = plain PnP)
+    cov = np.tile(np.eye(2) * 4.0, (9, 1, 1))
+    ev.evaluate_uncertainty(pts2d, cov, pose, "cat")
+    ev.evaluate_uncertainty_v2(pts2d, cov, pose, "cat")
+    assert ev.add_recorder[2:] == [True, True] and len(ev.uncertainty_pnp_cost) == 1
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pn1,pn2,dim,dup", [(5000, 7000, 3, 50), (3000, 200, 3, 10), (1, 33, 3, 0), (257, 256, 2, 5),
+                                             (4097, 9000, 2, 100), (20000, 17, 3, 3)])
+def test_nearest_point_idx_equals_the_oracle(pn1, pn2, dim, dup):
+    """single-slice and multi-slice launches (few queries -> the reference cloud is split over workgroups and merged by a
+    packed 64-bit atomicMin), ragged tiles, exact ties: indices must EQUAL the oracle's, not just the distances"""
+    ref, que = clouds(pn1, pn2, dim, pn1 + pn2, dup=min(dup, pn1 // 2, pn2))
+    got = E.nearest_point_idx(torch.from_numpy(ref).to(dev()), torch.from_numpy(que).to(dev())).cpu().numpy()
+    np.testing.assert_array_equal(got, nn_oracle.find_nearest_point_idx(ref, que))
+    np.testing.assert_array_equal(E.find_nearest_point_idx(ref, que), got)  # the reference-shaped numpy wrapper
+
+
+@pytest.mark.gpu
+def test_nearest_point_idx_batched_exclude_self_and_launcher():
+    b, pn, dim = 3, 1500, 3
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-1, 1, (b, pn, dim)).astype(np.float32)
+    pts[:, 700:720] = pts[:, :20]  # twins
+    t = torch.from_numpy(pts).to(dev())
+    got = E.nearest_point_idx(t, t, exclude_self=True).cpu().numpy()
+    for bi in range(b):
+        np.testing.assert_array_equal(got[bi], nn_oracle.find_nearest_point_idx(pts[bi], pts[bi], exclude_self=True))
+    assert (E.nearest_point_idx(t, t).cpu().numpy()[:, :700] == np.arange(700)).all()  # without it: itself (first copy)
+    # the reference's own launcher symbol, host pointers in and out (extend_utils.py:51-58)
+    lib = voting.load_library()
+    ref, que = clouds(900, 1100, 2, 9, dup=7)
+    idxs = np.zeros((1, 1100), np.int32)
+    lib.findNearestPointIdxLauncher.restype = None
+    lib.findNearestPointIdxLauncher(ref.ctypes.data_as(C.c_void_p), que.ctypes.data_as(C.c_void_p),
+                                    idxs.ctypes.data_as(C.c_void_p), 1, 900, 1100, 2, 0)
+    np.testing.assert_array_equal(idxs[0], nn_oracle.find_nearest_point_idx(ref, que))
+
+
+@pytest.mark.gpu
+def test_add_s_and_symmetric_projection_for_a_symmetric_object():
+    """a point set invariant under a 180-degree turn about z (the eggbox / glue situation): ADD of the turned pose is
+    large, ADD-S and the symmetric projection error vanish; the Evaluator routes the symmetric classes accordingly"""
+    rng = np.random.default_rng(2)
+    half = rng.uniform(-0.05, 0.05, (3000, 3))
+    model = np.concatenate([half, half * np.array([-1.0, -1.0, 1.0])])  # C2 symmetry about the z axis
+    pose = np.concatenate([P.rodrigues(np.array([0.3, 0.1, -0.2])), np.array([[0.01], [0.02], [0.7]])], 1)
+    turn = np.diag([-1.0, -1.0, 1.0])
+    turned = np.concatenate([pose[:, :3] @ turn, pose[:, 3:]], 1)
+    add = P.add_error(turned, pose, model)
+    adds = P.add_error(turned, pose, model, symmetric=True)
+    assert add > 0.03 and adds < 1e-6
+    # ADD-S against float64 brute force on a perturbed pose (a real nearest-neighbour problem)
+    pert = np.concatenate([P.rodrigues(np.array([0.31, 0.08, -0.22])), np.array([[0.012], [0.018], [0.71]])], 1)
+    a, b = model @ pert[:, :3].T + pert[:, 3], model @ pose[:, :3].T + pose[:, 3]
+    d_kd, _ = cKDTree(a).query(b)
+    assert abs(P.add_error(pert, pose, model, symmetric=True) - d_kd.mean()) < 1e-6
+    assert P.add_error(pert, pose, model, symmetric=True) <= P.add_error(pert, pose, model) + 1e-12
+    p2 = P.projection_2d_error(turned, pose, model, P.LINEMOD_K, symmetric=True)
+    assert p2 < 1e-3 and P.projection_2d_error(turned, pose, model, P.LINEMOD_K) > 5
+    kp3d = np.concatenate([rng.uniform(-0.05, 0.05, (8, 3)), np.zeros((1, 3))])
+    diam = 0.15
+    ev = E.Evaluator(models={"eggbox": model, "cat": model}, diameters={"eggbox": diam, "cat": diam},
+                     points_3d={"eggbox": kp3d, "cat": kp3d})
+    pts2d = P.project(kp3d, turned, P.LINEMOD_K)  # a detector that found the turned pose
+    ev.evaluate(pts2d, pose, "eggbox")  # symmetric class: ADD-S -> correct
+    ev.evaluate(pts2d, pose, "cat")     # ordinary class: ADD -> wrong
+    assert ev.add_recorder == [True, False]

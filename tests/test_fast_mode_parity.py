@@ -132,12 +132,12 @@ def _field_case(b=2, h=120, w=160, radius=18, first=4000):
     return mask, planar, kpts
 
 
-@pytest.mark.parametrize("scale", [2.0 ** -10, 2.0 ** 10, 2.0 ** 40])
+@pytest.mark.parametrize("scale", [2.0 ** -4, 2.0 ** 10, 2.0 ** 40])
 def test_power_of_two_field_scale_changes_nothing(scale):
     """the predicate is scale-invariant in |u| and the per-record scale is an exact exponent shift: a field multiplied
     by a power of two gives bit-identical inlier counts, in both modes, for every hypothesis that the scaling leaves
     bit-identical (hypothesis generation has absolute 1e-6 determinant gates upstream, kernel.cu:42: a scaled field
-    moves pairs across them, nothing else changes)"""
+    moves pairs across them, nothing else changes -- at 2^-10 every pair of unit vectors would fall below the gate)"""
     mask, planar, _ = _field_case()
     m, v = to_dev(mask, planar)
     ms, vs = to_dev(mask, (planar * np.float32(scale)).astype(np.float32))

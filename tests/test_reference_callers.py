@@ -108,8 +108,8 @@ def test_reference_wrappers_on_the_hip_layer(demo_fixture):
                 # the tensors handed over are of the recorded kind: int64 arg-max mask, strided [b,h,w,vn,2] view
                 assert str(mask.dtype) == m_spec["dtype"] and mask.is_contiguous() == m_spec["contiguous"]
                 assert str(vertex.dtype) == v_spec["dtype"] and vertex.is_contiguous() == v_spec["contiguous"]
-                assert tuple(vertex.stride()) == (2 * vn * h * w, w, 1, 2 * h * w, h * w)
-                assert np.argsort(v_spec["stride"]).tolist() == np.argsort(list(vertex.stride())).tolist()
+                assert tuple(vertex.stride())[1:] == (w, 1, 2 * h * w, h * w)  # (dim 0 has size 1 here: any stride)
+                assert np.argsort(v_spec["stride"][1:]).tolist() == np.argsort(list(vertex.stride())[1:]).tolist()
                 fn = getattr(voting, call["function"])
                 args = [mask, vertex]
                 if call["function"] == "estimate_voting_distribution_with_mean":

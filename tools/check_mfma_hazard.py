@@ -33,7 +33,7 @@ def compile_to_asm(out):
     sys.path.insert(0, ROOT)
     from pvnet_amd import build as B
     flags = [f for f in B.flags() if f not in ("-shared", "-fPIC")]
-    cmd = [B.hipcc_path()] + flags + ["-S", "--cuda-device-only", "-Wno-unused-command-line-argument"] + B.SRC + ["-o", out]
+    cmd = [B.hipcc_path()] + flags + ["-S", "--cuda-device-only", "-Wno-unused-command-line-argument", B.SRC[0], "-o", out]
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
 
 

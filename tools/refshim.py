@@ -166,13 +166,13 @@ def _wire_cv2(cv2):
         x = np.asarray(x, np.float64)
         if x.size == 3:
             return P.rodrigues(x.reshape(3)), None
-        return P.rotation_to_rodrigues(x.reshape(3, 3)).reshape(3, 1), None
+        return P.rodrigues_inv(x.reshape(3, 3)).reshape(3, 1), None
 
     def solvePnP(points_3d, points_2d, camera_matrix, dist_coeffs, flags=None, **kw):
         from pvnet_amd import pnp as P
         pose = P.pnp(np.asarray(points_3d, np.float64).reshape(-1, 3), np.asarray(points_2d, np.float64).reshape(-1, 2),
                      np.asarray(camera_matrix, np.float64))
-        rvec = P.rotation_to_rodrigues(pose[:, :3]).reshape(3, 1)
+        rvec = P.rodrigues_inv(pose[:, :3]).reshape(3, 1)
         return True, rvec, pose[:, 3].reshape(3, 1)
 
     cv2.Rodrigues = Rodrigues
