@@ -73,7 +73,8 @@ typedef struct PvnetVoteLayout {
                                                            key-point (fast mode: zero when |u| < 1e-6, which never votes,
                                                            kernel.cu:121) -- the only per-pixel data, same in both modes */
     size_t off_hyp;         /* float2 [b][vn][hn_pad]      hypotheses                                       */
-    size_t off_partial;     /* uint16 [b][vn][max_chunks][hn_pad]  per-chunk inlier counts                  */
+    size_t off_partial;     /* uint16 [b][vn][max_chunks][hn_pad]  per-chunk inlier counts -- EMPTY by default: the
+                               scoring kernel adds its counts into `counts` with integer atomics (PVNET_SCORE_ATOMIC=1) */
     size_t off_counts;      /* int32  [b][vn][hn_pad]      inlier count of every hypothesis                 */
     size_t off_win;         /* int32  [b][vn][2]           (winner index, winner count)                     */
     size_t off_seg;         /* int32  [2][b][nseg]         foreground count of every 4096-pixel segment     */

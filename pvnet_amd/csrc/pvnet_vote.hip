@@ -82,7 +82,7 @@ struct VoteParams {
     int mask_dtype, mask_linear, num_classes;
     const float* vertex;
     int64_t vs0, vs1, vs2, vs3, vs4;
-    int b, h, w, vn, hn, npix, words, cap, chunk, max_chunks, hpl, hgroups, hn_pad, wg_g, wg_s, mode, score_xcd;
+    int b, h, w, vn, hn, npix, words, cap, chunk, max_chunks, hpl, hgroups, hn_pad, wg_g, wg_s, mode, score_xcd, atomic_counts;
     float thresh, tau;
     int min_num, max_num;
     uint64_t seed;
@@ -568,6 +568,7 @@ __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
         hyp_intersect(d0.x, d0.y, q0.x, q0.y, d1.x, d1.y, q1.x, q1.y, hx, hy);
     }
     P.hyp[((size_t)bi * P.vn + k) * P.hn_pad + h] = make_float2(hx, hy);
+    if (P.atomic_counts) P.counts[((size_t)bi * P.vn + k) * P.hn_pad + h] = 0;  // K4 accumulates into it
     if (!LITERAL && P.mode) {  // the same hypothesis about the image's local origin, as a bf16x3 B operand column
         float ox = 0.f, oy = 0.f;
         if (live) {
@@ -695,9 +696,16 @@ __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
                 }
             }
         }
-        uint16_t* __restrict__ po = P.partial + (bk * P.max_chunks + c) * P.hn_pad + (size_t)hg * 64 * HPL;
+        if (P.atomic_counts) {  // integer atomics straight into the count of every hypothesis (order-independent)
+            int32_t* pc = P.counts + bk * P.hn_pad + (size_t)hg * 64 * HPL;
 #pragma unroll
-        for (int j = 0; j < HPL; ++j) po[j * 64 + lane] = (uint16_t)(int)cnt[j];  // exact: counts < 2^24
+            for (int j = 0; j < HPL; ++j)
+                if ((int)cnt[j] > 0) atomicAdd(pc + j * 64 + lane, (int)cnt[j]);
+        } else {
+            uint16_t* __restrict__ po = P.partial + (bk * P.max_chunks + c) * P.hn_pad + (size_t)hg * 64 * HPL;
+#pragma unroll
+            for (int j = 0; j < HPL; ++j) po[j * 64 + lane] = (uint16_t)(int)cnt[j];  // exact: counts < 2^24
+        }
     }
 }
 
@@ -746,12 +754,12 @@ constexpr int VOTE_WRAP = 512;  // vote8 accumulators hold their count mod 512
 __device__ __forceinline__ int votes_of(unsigned acc) { return (int)(((acc >> 23) * 383u) & 511u); }
 
 // TIMED (profiling entry pvnet_vote_v3_stage_repeat only): every workgroup stores the constant-rate device clock at its
-// first and last instruction into its own slot of the (idle during this stage) `counts` buffer -- two plain 8-byte
+// first and last instruction into its own slot of the (idle during this stage) `pix` buffer -- two plain 8-byte
 // stores per workgroup; max end - min start over the slots is the kernel's duration as a kernel trace reports it,
 // measured live and free of launch gaps.
 template <int MH, bool TIMED>
 __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
-    unsigned long long* __restrict__ stamps = reinterpret_cast<unsigned long long*>(P.counts);
+    unsigned long long* __restrict__ stamps = reinterpret_cast<unsigned long long*>(P.pix);
     if (TIMED && threadIdx.x == 0) stamps[2 * blockIdx.x] = (unsigned long long)wall_clock64();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* s_t = reinterpret_cast<uint4*>(smem);
@@ -832,7 +840,11 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
         for (int t = 0; t < MH; ++t) {
             const int ci = votes_of(cnt[t]);
             const int c = ci + __shfl_xor(ci, 32, 64);  // the half-waves hold different rows of the column
-            if (half == 0) po[t * 32 + col] = (uint16_t)c;
+            if (P.atomic_counts) {
+                if (half == 0 && c > 0) atomicAdd(P.counts + bk * P.hn_pad + h0 + t * 32 + col, c);
+            } else if (half == 0) {
+                po[t * 32 + col] = (uint16_t)c;
+            }
         }
     }
     if (TIMED) {
@@ -898,6 +910,13 @@ __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
     // (one 32-bit load per chunk row) with eight loads in flight: the rows are latency-, not bandwidth-bound.
     unsigned long long best = 0;
     const size_t row = (size_t)(P.hn_pad >> 1);  // hn_pad is even
+    if (P.atomic_counts) {  // K4 already summed: one value per hypothesis
+        for (int h = threadIdx.x; h < P.hn; h += RT) {
+            const uint32_t c = (uint32_t)P.counts[bk * P.hn_pad + h];
+            const unsigned long long key = ((unsigned long long)c << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)h);
+            best = key > best ? key : best;
+        }
+    } else
     for (int h2 = threadIdx.x; 2 * h2 < P.hn; h2 += RT) {
         const uint32_t* pp = reinterpret_cast<const uint32_t*>(P.partial + bk * P.max_chunks * P.hn_pad) + h2;
         int lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
@@ -1204,6 +1223,8 @@ struct Tuning {
     int chunk;          // PVNET_SCORE_CHUNK       pixels per count row
     int compact_kg;     // PVNET_COMPACT_KG        key-points per compaction block
     int score_xcd;      // PVNET_SCORE_XCD         1: contiguous eighths of the work-item list per XCD (L2 affinity)
+    int score_atomic;   // PVNET_SCORE_ATOMIC      1 (default): K4 adds its counts into `counts` with integer atomics;
+                        //                         0: per-chunk uint16 count rows (`partial`) summed by K5
     int dev_stages;     // PVNET_DEV_STAGES        development aid: bit mask of the stages to launch
     int cus;            // compute units of the device (all GPUs of a node are the same part)
 };
@@ -1214,6 +1235,7 @@ void load_tuning(Tuning& t) {
     t.chunk = env_int("PVNET_SCORE_CHUNK", -1);
     t.compact_kg = env_int("PVNET_COMPACT_KG", 3);
     t.score_xcd = env_int("PVNET_SCORE_XCD", 1);
+    t.score_atomic = env_int("PVNET_SCORE_ATOMIC", 1);
     t.dev_stages = env_int("PVNET_DEV_STAGES", 0x3F);
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -1376,6 +1398,7 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     P.hpl = L.hpl; P.hgroups = L.hgroups; P.hn_pad = L.hn_pad; P.wg_g = L.wg_g; P.wg_s = L.wg_s;
     P.mode = L.reserved_;
     P.score_xcd = tuning().score_xcd;
+    P.atomic_counts = tuning().score_atomic;
     P.thresh = thresh;
     P.tau = (thresh > 0.f && thresh < 1.f) ? (float)(sqrt(1.0 - (double)thresh * thresh) / (double)thresh) : 0.f;
     P.min_num = min_num; P.max_num = max_num; P.seed = seed; P.image_base = image_base; P.idxs = idxs; P.flags = flags;
@@ -1459,7 +1482,8 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     L->off_rec = take(sizeof(float) * 4 * (size_t)b * vn * cap);
     L->off_hyp = take(sizeof(float) * 2 * (size_t)b * vn * L->hn_pad);
     L->off_hypb = take(mode ? sizeof(uint4) * 2 * (size_t)b * vn * L->hn_pad : 0);
-    L->off_partial = take(sizeof(uint16_t) * (size_t)b * vn * L->max_chunks * L->hn_pad);
+    // per-chunk count rows exist only when K4 does not add into `counts` directly (PVNET_SCORE_ATOMIC=0)
+    L->off_partial = take(T.score_atomic ? 0 : sizeof(uint16_t) * (size_t)b * vn * L->max_chunks * L->hn_pad);
     L->off_counts = take(sizeof(int32_t) * (size_t)b * vn * L->hn_pad);
     L->off_win = take(sizeof(int32_t) * 2 * (size_t)b * vn);
     L->total_bytes = off;
@@ -1554,17 +1578,19 @@ int pvnet_vote_v3_stage_repeat(const void* mask, int mask_dtype, const int64_t m
     for (int i = 0; rc == 0 && i < repeats; ++i) rc = launch_all(P, s, nullptr, 1 << stage);
     if (rc == 0) rc = (int)hipEventRecord(ev[1], s);
     // the matrix-pipe scoring kernel once more, `repeats` times, stamping the device clock itself (fast mode only)
-    const bool device_clock = stage == PVNET_STAGE_SCORE && !(P.flags & PVNET_F_LITERAL) && P.mode;
-    // ticks accumulate in the spare words of ctrl's global row; the stamps live in `counts` (rewritten by K5 anyway)
+    // ticks accumulate in the spare words of ctrl's global row; the stamps live in `pix` (consumed by K3 only; a later
+    // complete call rewrites it), when the scoring grid's slots fit there
+    const long long score_wgs = tuning().wgs_per_cu > 0 ? (long long)tuning().cus * tuning().wgs_per_cu : (1ll << 40);
+    const bool device_clock = stage == PVNET_STAGE_SCORE && !(P.flags & PVNET_F_LITERAL) && P.mode &&
+                              score_wgs * 16 <= (long long)sizeof(int32_t) * P.b * P.cap;
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(P.ctrl + P.b * CTRL_STRIDE + 2);
     if (rc == 0 && device_clock) {
         for (int i = 0; rc == 0 && i < repeats; ++i) {
             int grid = 0;
             rc = launch_all(P, s, nullptr, 1 << stage, true, &grid);
-            if ((size_t)grid * 16 > sizeof(int32_t) * (size_t)P.b * P.vn * P.hn_pad) rc = PVNET_E_UNSUPPORTED;
             if (rc == 0)
                 hipLaunchKernelGGL(ts_collect_kernel, dim3(1), dim3(256), 0, s,
-                                   reinterpret_cast<const unsigned long long*>(P.counts), grid, acc, i == 0 ? 1 : 0);
+                                   reinterpret_cast<const unsigned long long*>(P.pix), grid, acc, i == 0 ? 1 : 0);
         }
         if (rc == 0) rc = (int)hipGetLastError();
     }

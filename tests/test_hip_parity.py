@@ -577,6 +577,7 @@ def test_concurrent_streams_reproduce_serial_results():
     {"PVNET_SCORE_HPL": "2"}, {"PVNET_SCORE_HPL": "4"},        # fewer hypotheses per work item (MH = 2, 4)
     {"PVNET_COMPACT_KG": "1"}, {"PVNET_COMPACT_KG": "9"},
     {"PVNET_SCORE_XCD": "0"},                                  # work items strided over the grid, no XCD affinity
+    {"PVNET_SCORE_ATOMIC": "1"}, {"PVNET_SCORE_ATOMIC": "0"},  # counts by integer atomics / by per-group count rows
 ])
 def test_launch_knobs_do_not_change_results(knobs, monkeypatch):
     """Tuning knobs re-shape grids and work items, never results: literal mode stays bit-equal to
