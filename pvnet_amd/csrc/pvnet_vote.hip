@@ -1223,6 +1223,9 @@ struct Tuning {
     int chunk;          // PVNET_SCORE_CHUNK       pixels per count row
     int compact_kg;     // PVNET_COMPACT_KG        key-points per compaction block
     int score_xcd;      // PVNET_SCORE_XCD         1: contiguous eighths of the work-item list per XCD (L2 affinity)
+    int score_lds_kb;   // PVNET_SCORE_LDS_KB      experiment: pad the matrix-pipe kernel's dynamic LDS to this many KB, which
+                        //                         caps its resident workgroups per CU (160 KB / value) and leaves registers
+                        //                         for other streams' small stages; 0 = no padding
     int score_atomic;   // PVNET_SCORE_ATOMIC      1 (default): K4 adds its counts into `counts` with integer atomics;
                         //                         0: per-chunk uint16 count rows (`partial`) summed by K5
     int dev_stages;     // PVNET_DEV_STAGES        development aid: bit mask of the stages to launch
@@ -1236,6 +1239,7 @@ void load_tuning(Tuning& t) {
     t.compact_kg = env_int("PVNET_COMPACT_KG", 3);
     t.score_xcd = env_int("PVNET_SCORE_XCD", 1);
     t.score_atomic = env_int("PVNET_SCORE_ATOMIC", 1);
+    t.score_lds_kb = env_int("PVNET_SCORE_LDS_KB", 0);
     t.dev_stages = env_int("PVNET_DEV_STAGES", 0x3F);
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -1338,7 +1342,8 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
         if (score_grid) *score_grid = (int)wgs;
         if (!literal && P.mode) {
             const int mh = P.wg_g * P.hpl / 2;  // hypotheses per item = wg_g * 64 * hpl = 4 waves * mh * 32
-            const size_t lds = (size_t)(P.wg_s * P.chunk / 32) * TILE_U4 * sizeof(uint4);
+            size_t lds = (size_t)(P.wg_s * P.chunk / 32) * TILE_U4 * sizeof(uint4);
+            if (T.score_lds_kb > 0 && T.score_lds_kb <= 64 && lds < (size_t)T.score_lds_kb * 1024) lds = (size_t)T.score_lds_kb * 1024;
             const dim3 g((unsigned)wgs), t(256);
             if (timed_score) {  // same code + two clock stamps per workgroup (pvnet_vote_v3_stage_repeat)
                 switch (mh) {
