@@ -18,8 +18,8 @@
 //                     consecutive addresses) and writes ONE float4 record per (pixel, key-point):
 //                     (x, y, ux, uy), the raw direction                                                 [HBM read]
 //   K3 hypotheses     one thread per (image, kp, h): two pixel draws (counter RNG or caller idxs), 2x2 solve in
-//                     the reference's float32 order; also writes each hypothesis as a bf16x3 MFMA operand column;
-//                     one extra block per image plans the scoring work items
+//                     the reference's float32 order; also writes each hypothesis as a bf16x3 MFMA operand column and
+//                     zeroes its inlier count; one extra block per image plans the scoring work items
 //   K4 score          DOMINANT.  Fast mode (score_mfma_kernel): the vote is two 3-term fp32 dot products and a
 //                     compare; every operand is split into three bf16 parts, so each dot product is ONE
 //                     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (fp32-equivalent accuracy, measured), and
@@ -29,8 +29,10 @@
 //                     LDS once per work item.
 //                     Literal mode (score_kernel<HPL,true>): "lane owns hypotheses" on the VALU in the
 //                     reference's float32 operation order, bit-exact with the reference's kernels.
-//                     Work items are strided over a persistent grid; counts go out as uint16 rows.
-//   K5 select+refine  sums the chunk counts, arg-max with first-index tie-break (wave shuffles), recomputes the
+//                     Work items go to a persistent grid XCD by XCD (one contiguous eighth of the list per XCD: the
+//                     operands of an (image, key-point) pass through one L2); counts are added into
+//                     counts[b][vn][hn] with integer atomics (zeroed by K3; order-independent, deterministic).
+//   K5 select+refine  arg-max over the counts with first-index tie-break (wave shuffles), recomputes the
 //                     winner's inliers and solves the 2x2 normal equations, accumulated in float64 centred on
 //                     the winner (the reference's un-centred float32 sums are ~2e-3 px noisy).
 //
@@ -600,7 +602,8 @@ __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
 // 16-byte load per thread), turn them into the expanded-form constants about the image origin and park them in
 // LDS; every wave then reads them back as broadcast ds_read_b128 + ds_read_b64 (all lanes the same address:
 // conflict-free, LDS pipe, not VALU) -- the 4 waves cover G hypothesis groups x S chunks.  Work items are strided
-// over a persistent grid; the per-chunk counts leave as coalesced uint16 rows.  At batch 32 the kernel issues
+// over a persistent grid; the counts leave as integer atomic adds (or, PVNET_SCORE_ATOMIC=0, as coalesced uint16 rows
+// per chunk).  At batch 32 the kernel issues
 // ~139 M VALU wave-instructions in ~150 us = ~91 % of the 2-cycles-per-instruction bound at the 1.97 GHz it
 // sustains (profiles/r01_streamk_experiment.txt), so what is left is the op count, not the schedule.
 // ------------------------------------------------------------------------------------------------------------
@@ -834,7 +837,7 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
             Acr = Ncr;
             Adt = Ndt;
         }
-        // the group's row of counts (uint16: <= wg_s * chunk votes); K5 sums one row per chunk GROUP in this mode
+        // the group's counts: atomic adds into counts[] (default), or one uint16 row per chunk GROUP for K5 to sum
         uint16_t* po = P.partial + (bk * P.max_chunks + cg) * P.hn_pad + h0;
 #pragma unroll
         for (int t = 0; t < MH; ++t) {
