@@ -12,8 +12,9 @@ A "step" is one pass of the whole voting path (mask + 9-key-point vector field -
 synthetic images per GPU, inputs resident in HBM.  Steps are independent batches, so they are issued round-robin on
 --streams HIP streams (default 6); `single_stream` in the output is the same K steps issued strictly one after the
 other (the per-batch latency a caller with ONE frame in flight sees).  With N > 1 every rank votes its own 32 images
-(weak scaling, no data-path collective) and the step ends with the path's one real exchange: an RCCL all-gather of the
-[32, 9, 2] key-points.  Rank 0 prints ONE JSON line.
+(weak scaling, no data-path collective) and its key-points leave through the path's one real exchange, an RCCL
+all-gather of [32, 9, 2] per step -- bucketed: the key-points of --gather-bucket consecutive steps (default: one per
+stream) are voted straight into a staging block and travel in ONE collective.  Rank 0 prints ONE JSON line.
 
 Besides the contract's fields the line carries
   roofline      the dominant kernel (inlier scoring, score_mfma_kernel), compute bound.  Its duration is
@@ -82,6 +83,9 @@ def parse(argv=None):
     ap.add_argument("--clean", action="store_true", help="noise-free field (default: noisy, net-like background)")
     ap.add_argument("--streams", type=int, default=6,
                     help="HIP streams the steps are issued on round-robin (independent batches in flight)")
+    ap.add_argument("--gather-bucket", type=int, default=0,
+                    help="steps whose key-points travel in ONE all-gather (N > 1 or under torch.distributed.run); 0 = the "
+                         "number of streams")
     ap.add_argument("--score-repeats", type=int, default=200, help="back-to-back scoring launches timed for the roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -321,32 +325,68 @@ def main(argv=None):
     voting.load_library()
 
     sets = make_inputs(rank, a.buffers, a.radius, not a.clean, dev)
-    # S streams, S + 1 gather targets: the 2.3 KB all-gather of step i (RCCL stream) overlaps the voting of the
-    # following steps; a target is reused only after the gather that last wrote it has been waited for
+    # S streams.  The path's one exchange -- the all-gather of every step's [32, 9, 2] key-points -- is BUCKETED: the
+    # key-points of G consecutive steps (default G = S) are voted straight into the slots of a staging block and sent by
+    # ONE RCCL all-gather of G x 2.3 KB per rank (fewer, larger collectives: a 2.3 KB gather is pure launch latency, and
+    # one per step costs the host more than the voting's six launches).  Two staging / target blocks alternate; a block is
+    # rewritten only after the gather that read it has completed (event on the communication stream).
     nstreams = max(1, a.streams)
     streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
-    gathered = [torch.empty((world * BATCH, VN, 2), dtype=torch.float32, device=dev) for _ in range(nstreams + 1)] \
-        if dist is not None else None
+    G = max(1, a.gather_bucket if a.gather_bucket > 0 else nstreams)
+    if dist is not None:
+        comm = torch.cuda.Stream(dev)
+        staging = [torch.empty((G, BATCH, VN, 2), dtype=torch.float32, device=dev) for _ in range(2)]
+        gathered = [torch.empty((world, G, BATCH, VN, 2), dtype=torch.float32, device=dev) for _ in range(2)]
+        voted = [[torch.cuda.Event() for _ in range(G)] for _ in range(2)]
+        sent = [None, None]  # event: the gather that last read staging[blk] is done
+    bucket = {"n": 0, "fill": 0}  # index of the bucket being filled, slots filled
     pending = []
+
+    def flush():
+        """send the filled slots of the current bucket (all G of them, except for a last partial bucket)"""
+        blk, k = bucket["n"] % 2, bucket["fill"]
+        if k == 0:
+            return
+        with torch.cuda.stream(comm):
+            for j in range(k):
+                comm.wait_event(voted[blk][j])
+            src = staging[blk] if k == G else staging[blk][:k].contiguous()
+            dst = gathered[blk] if k == G else torch.empty((world, k, BATCH, VN, 2), dtype=torch.float32, device=dev)
+            w = dist.all_gather_into_tensor(dst, src, async_op=True)
+            w.wait()  # comm stream waits for the collective
+            sent[blk] = torch.cuda.Event()
+            sent[blk].record(comm)
+        pending.append(sent[blk])
+        del pending[:-4]  # (older gathers are ordered before these on the communication stream)
+        bucket["n"] += 1
+        bucket["fill"] = 0
 
     def step(i, ns=nstreams, **kw):
         m, v, _, _ = sets[i % len(sets)]
         if kw:  # profiled / debug calls: current stream, synchronising
             return voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=SEED0 + i,
                                                  image_offset=rank * BATCH, **kw)
-        with torch.cuda.stream(streams[i % ns]):
+        st = streams[i % ns]
+        with torch.cuda.stream(st):
+            if dist is None:
+                return voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=SEED0 + i,
+                                                     image_offset=rank * BATCH)
+            blk, j = bucket["n"] % 2, bucket["fill"]
+            if sent[blk] is not None:
+                st.wait_event(sent[blk])  # the gather that last read this block has completed
             out = voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=SEED0 + i,
-                                                image_offset=rank * BATCH)
-            if dist is not None:
-                # the path's single exchange: RCCL all-gather of the [32, 9, 2] key-points over xGMI
-                pending.append(dist.all_gather_into_tensor(gathered[i % (nstreams + 1)], out, async_op=True))
-                if len(pending) > ns:
-                    pending.pop(0).wait()
+                                                image_offset=rank * BATCH, out=staging[blk][j])
+            voted[blk][j].record(st)
+        bucket["fill"] += 1
+        if bucket["fill"] == G:
+            flush()
         return out
 
     def fence():
+        if dist is not None:
+            flush()
         while pending:
-            pending.pop(0).wait()
+            pending.pop(0).synchronize()
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
@@ -389,12 +429,10 @@ def main(argv=None):
         allt = torch.empty((world,), dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(allt, t)
         per_rank = [BATCH * a.steps / float(x) for x in allt.tolist()]
-        out = voting.ransac_voting_layer_v3(sets[0][0], sets[0][1], HN, inlier_thresh=THRESH, seed=SEED0,
-                                            image_offset=rank * BATCH)
         fence()
         t0 = time.perf_counter()
-        for i in range(50):  # the exchange alone, one after the other: its latency (2.3 KB per rank)
-            dist.all_gather_into_tensor(gathered[0], out)
+        for i in range(50):  # the exchange alone, one bucket after the other: its latency (G x 2.3 KB per rank)
+            dist.all_gather_into_tensor(gathered[0], staging[0])
         torch.cuda.synchronize(dev)
         gather_ms = (time.perf_counter() - t0) / 50 * 1e3
         dist.barrier()
@@ -439,6 +477,7 @@ def main(argv=None):
                              "note": "PVNET_F_LITERAL: the reference's float32 operation order, bit-exact with its "
                                      "kernels (5 synchronising calls on one stream)"},
             "per_rank_votings_per_s": per_rank, "gather_ms": gather_ms,
+            "gather_bucket_steps": G if dist is not None else None,
             "dtype": "bf16x3 products, f32 accumulate (f32-equivalent; refinement f64)", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[2]: batch=32 synthetic 480x640 fields per GPU, 9 keypoints, "
                                    "1024 hypotheses, inlier_thresh 0.99, int64 mask, planar strided field",

@@ -201,7 +201,7 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
                            min_num=5, max_num=30000, *, idxs: Optional[torch.Tensor] = None,
                            seed: Optional[int] = None, image_offset: int = 0, literal: bool = False, refine: bool = True,
                            return_status: bool = False, return_debug: bool = False, stage_times: bool = False,
-                           workspace: Optional[torch.Tensor] = None):
+                           workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
     """Drop-in for the reference's ``ransac_voting_layer_v3`` (ransac_voting_gpu.py:514-598).
 
     :param mask:      [b,h,w]  any integer / bool / float dtype; foreground <=> ``mask.byte() != 0``
@@ -223,6 +223,8 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
       refine  False skips the least-squares refinement (:579-595) and returns the winning hypotheses
       return_status / return_debug / stage_times: also return the per-(image,kp) status bits / typed views of
               the workspace / per-stage GPU milliseconds (synchronises; for bench.py)
+      out     a caller-owned float32 CUDA tensor [b,vn,2] (contiguous) to receive the key-points instead of a fresh one
+              (e.g. a slot of a staging buffer that a later collective sends)
       workspace  a caller-owned uint8 CUDA tensor of >= ``vote_layout(...).total_bytes`` bytes to use instead of a
               fresh allocation (the caller then guarantees that no other call in flight on another stream uses it);
               ``VotePlan`` wraps this for repeated calls of one shape
@@ -237,7 +239,11 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
     L = vote_layout(b, h, w, vn, hn, max_num)
     with torch.cuda.device(dev):
         ws = _workspace(workspace, L, dev)
-        out = torch.empty((b, vn, 2), dtype=torch.float32, device=dev)
+        if out is None:
+            out = torch.empty((b, vn, 2), dtype=torch.float32, device=dev)
+        elif not (out.is_cuda and out.device == dev and out.dtype == torch.float32 and out.is_contiguous() and
+                  tuple(out.shape) == (b, vn, 2)):
+            raise RuntimeError(f"out must be a contiguous float32 CUDA tensor of shape {(b, vn, 2)} on {dev}")
         status = torch.empty((b, vn), dtype=torch.int32, device=dev) if (return_status or return_debug) else None
         stream = torch.cuda.current_stream(dev).cuda_stream
         args = [C.c_void_p(mask.data_ptr()), _MASK_CODES[mask.dtype], _strides(mask, 3),

@@ -267,6 +267,11 @@ def test_vote_plan_matches_the_plain_call():
     ws = torch.empty(plan.layout.total_bytes, dtype=torch.uint8, device=dev())
     c = voting.ransac_voting_layer_v3(m, v, 512, inlier_thresh=0.99, seed=2, workspace=ws)
     assert torch.equal(c, b)
+    slot = torch.zeros((3, 1, 9, 2), device=dev())  # out=: vote straight into a slot of a staging block
+    d = voting.ransac_voting_layer_v3(m, v, 512, inlier_thresh=0.99, seed=2, out=slot[1])
+    assert d.data_ptr() == slot[1].data_ptr() and torch.equal(slot[1], b) and (slot[0] == 0).all() and (slot[2] == 0).all()
+    with pytest.raises(RuntimeError, match="out must be"):
+        voting.ransac_voting_layer_v3(m, v, 512, inlier_thresh=0.99, seed=2, out=slot[:, 0])
     with pytest.raises(RuntimeError, match="workspace"):
         voting.ransac_voting_layer_v3(m, v, 512, inlier_thresh=0.99, seed=2, workspace=ws[:1000])
     with pytest.raises(RuntimeError, match="VotePlan"):
