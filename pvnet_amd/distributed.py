@@ -51,7 +51,10 @@ def sharded_ransac_voting_layer_v3(mask: torch.Tensor, vertex: torch.Tensor, rou
 
     ``mask`` / ``vertex`` hold only this rank's shard (``shard_range(total, world, rank)``); ``total`` defaults to
     ``world * b_local``.  ``voter`` defaults to the HIP layer; (CPU tests inject a checker here).  The per-image
-    RNG stream is the GLOBAL image index, so results do not depend on how the batch was sharded."""
+    RNG stream is the GLOBAL image index, so results do not depend on how the batch was sharded -- given ONE seed for
+    the whole batch: an explicit ``seed`` is used as it is; with ``seed=None`` rank 0 draws one from its CPU generator
+    and broadcasts it (one int64), so the default call is shard-invariant too and ``torch.manual_seed`` on rank 0
+    makes it repeatable at any world size."""
     if voter is None:
         from .voting import ransac_voting_layer_v3 as voter
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -60,8 +63,14 @@ def sharded_ransac_voting_layer_v3(mask: torch.Tensor, vertex: torch.Tensor, rou
     total = world * b_local if total is None else total
     start, end = shard_range(total, world, rank)
     assert end - start == b_local, f"rank {rank} holds {b_local} images but owns [{start},{end})"
-    if seed is not None:
-        kw["seed"] = seed
+    if seed is None:
+        t = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)  # drawn on every rank (keeps the generators in step) ...
+        if world > 1:
+            if dist.get_backend(group) == "nccl":
+                t = t.to(mask.device)
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        seed = int(t.item())  # ... rank 0's draw is the one every rank uses
+    kw["seed"] = seed
     kw["image_offset"] = start
     local = voter(mask, vertex, round_hyp_num, *args, **kw)
     return gather_keypoints(local, total, group) if world > 1 else local

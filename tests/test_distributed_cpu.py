@@ -67,3 +67,46 @@ def test_two_ranks_reproduce_the_unsharded_batch(total):
     for r in range(2):
         assert res[r].shape == (total, 9, 2)
         np.testing.assert_array_equal(res[r], ref)  # same global RNG streams, same order, on every rank
+
+
+def _seed_echo_voter(mask, vertex, hn, *a, seed=0, image_offset=0, **kw):
+    """stub voter: every 'key-point' carries (seed mod 2^20, global image index) -- shows which seed a rank voted with"""
+    b, vn = mask.shape[0], vertex.shape[3]
+    out = torch.empty((b, vn, 2), dtype=torch.float32)
+    out[..., 0] = float(seed % (1 << 20))
+    out[..., 1] = torch.arange(image_offset, image_offset + b, dtype=torch.float32)[:, None]
+    return out
+
+
+def _worker_default_seed(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)  # the ranks' own generators DIFFER: only rank 0's draw may be used
+        mask = torch.ones((2, 4, 4), dtype=torch.int64)
+        vertex = torch.zeros((2, 4, 4, 3, 2))
+        full = D.sharded_ransac_voting_layer_v3(mask, vertex, 8, voter=_seed_echo_voter)  # seed=None
+        q.put((rank, full.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_default_seed_is_rank0s_draw_on_every_rank():
+    """ADVICE r01: with seed=None every rank used to draw its own seed, so the default call was not shard-invariant;
+    now rank 0's draw is broadcast"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_default_seed, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(res[0], res[1])
+    assert len(np.unique(res[0][..., 0])) == 1  # ONE seed for the whole batch
+    np.testing.assert_array_equal(res[0][:, 0, 1], np.arange(4))  # global image indices: RNG streams by global index
+    g = torch.Generator().manual_seed(100)
+    want = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, generator=g).item()) % (1 << 20)
+    assert int(res[0][0, 0, 0]) == want  # and it is rank 0's
