@@ -466,6 +466,8 @@ def main(argv=None):
         alg_tflops = FLOP_PER_PAIR * pairs / score_s / 1e12
         compulsory = BATCH * H * W * 8 + tn_per_batch * VN * 2 * 4  # the masks + the foreground vectors, per batch
         traffic = {k: measured_traffic(k) for k in PATH_KERNELS}
+        mfma_util = measured_mfma_util()
+        mfma_util_s = "n/a" if mfma_util is None else f"{mfma_util:.2f}"
         measured = sum(v for v in traffic.values() if v) if any(traffic.values()) else None
         res = {
             "metric": "RANSAC votings/s (480x640, 9 kpts, batch 32) + HBM GB/s vs roofline",
@@ -501,9 +503,12 @@ def main(argv=None):
                          "algorithmic_flop_per_pair": FLOP_PER_PAIR, "algorithmic_tflops": alg_tflops,
                          "vs_fp32_vector_peak": alg_tflops / PEAK_F32_TFLOPS,
                          "vs_bf16_peak": alg_tflops / PEAK_BF16_TFLOPS,
-                         "mfma_util": measured_mfma_util(),
+                         "mfma_util": mfma_util,
                          "mfma_util_source": os.path.basename(newest_profile("_pmc.json") or "") or None,
-                         "note": "frac = EXECUTED matrix flops (bf16x3 split, K = 15 of 16 slots: 64 flop per test) / "
+                         "note": f"exec {exec_tflops:.0f} TF = {exec_tflops / PEAK_BF16_TFLOPS:.2f} bf16 peak; algorithmic "
+                                 f"{alg_tflops:.0f} TF = {alg_tflops / PEAK_F32_TFLOPS:.2f}x fp32 vector = "
+                                 f"{alg_tflops / PEAK_BF16_TFLOPS:.3f} bf16; mfma_util {mfma_util_s}.  "
+                                 "frac = EXECUTED matrix flops (bf16x3 split, K = 15 of 16 slots: 64 flop per test) / "
                                  "2.5 PF; the same launch is 12 algorithmic fp32 flop per test (SURVEY 8d) = "
                                  "vs_fp32_vector_peak of the vector peak it left for the matrix pipe = vs_bf16_peak of "
                                  "the bf16 peak; mfma_util = matrix-pipe busy cycles / SIMD cycles (PMC)"},
@@ -519,7 +524,8 @@ def main(argv=None):
                              "dense_equivalent_gbs": BYTES_PER_VOTING * BATCH / step_s / 1e9,
                              "dense_equivalent_frac": BYTES_PER_VOTING * BATCH / step_s / 1e9 / PEAK_HBM_GBS,
                              "path_ms_serial": path_s * 1e3,
-                             "note": "compulsory = int64 masks + foreground vectors (what must cross HBM); measured = "
+                             "note": f"compulsory {compulsory / 1e6:.0f} MB, measured {(measured or 0) / 1e6:.0f} MB per batch; "
+                                     "compulsory = int64 masks + foreground vectors (what must cross HBM); measured = "
                                      "rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the six kernels (committed PMC pass); "
                                      "dense_equivalent = SURVEY 8d's 24 576 072 B per voting, the bytes a dense "
                                      "implementation streams -- NOT achieved bandwidth: the path never reads the "
