@@ -4,9 +4,11 @@ Restates lib/utils/extend_utils/src/nearest_neighborhood.cu:48-117 (findNearestP
 findNearestPoint2DIdxKernel): for every query the reference point of smallest squared distance, the distance evaluated
 in float32 in the source's operation order ((x1-x2)^2 + (y1-y2)^2 [+ (z1-z2)^2], one rounding per operation), a strict
 `dist < min_dist` scan from index 0 -- i.e. the FIRST minimum wins -- and index 0 when nothing qualifies.
-Only tests/ may import this module.  Parity pinning: the reference holds no test or golden vector for this function and
-its extension needs nvcc + cffi; the pin is the source itself (the kernel is 20 lines) plus scipy's cKDTree as an
-independent answer wherever the float32 minimum is unique (tests/test_evaluation.py)."""
+Only tests/ may import this module.  PARITY PINNING: the reference holds no test or golden vector for this function,
+so it is pinned by the reference's own device code: nearest_neighborhood.cu is compiled for gfx950 where it lies in the
+reference tree (`make -C oracle ref` -> oracle/_ref/libpvnet_refnn.so, through the header shim of oracle/ref_kernels/)
+and called through its own launcher `findNearestPointIdxLauncher` on the MI355X; tests/test_evaluation.py holds this
+restatement and the product equal to it index for index (ties included), and to scipy's cKDTree in distance."""
 import numpy as np
 
 

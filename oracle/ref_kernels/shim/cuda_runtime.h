@@ -11,4 +11,10 @@ typedef hipError_t cudaError_t;
 #define cudaSuccess hipSuccess
 #define cudaGetErrorString hipGetErrorString
 #define cudaGetLastError hipGetLastError
+/* ... and the five that lib/utils/extend_utils/src/nearest_neighborhood.cu's host launcher adds */
+#define cudaMalloc hipMalloc
+#define cudaFree hipFree
+#define cudaMemcpy hipMemcpy
+#define cudaMemcpyHostToDevice hipMemcpyHostToDevice
+#define cudaMemcpyDeviceToHost hipMemcpyDeviceToHost
 #endif

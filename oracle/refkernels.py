@@ -74,3 +74,30 @@ def voting_for_hypothesis(direct, coords, hypo_pts, inlier_thresh, contract: str
                                                  inl.data_ptr(), tn, vn, hn, float(inlier_thresh))
     assert rc == 0, f"hip error {rc}"
     return inl
+
+
+# ---- the reference's nearest-neighbour launcher (lib/utils/extend_utils/src/nearest_neighborhood.cu:120-160) --------
+_SO_NN = {"off": os.path.join(_HERE, "_ref", "libpvnet_refnn.so"), "fast": os.path.join(_HERE, "_ref", "libpvnet_refnn_fma.so")}
+_nn_libs = {}
+
+
+def nn_available(contract: str = "off") -> bool:
+    return os.path.exists(_SO_NN[contract])
+
+
+def find_nearest_point_idx(ref_pts, que_pts, exclude_self: bool = False, contract: str = "off"):
+    """numpy [pn1,dim] / [pn2,dim] float32 -> int32 [pn2] through the REFERENCE'S OWN `findNearestPointIdxLauncher`
+    (host pointers; it allocates and copies itself), exactly as extend_utils.py:51-58 calls it."""
+    import numpy as np
+    if contract not in _nn_libs:
+        L = C.CDLL(_SO_NN[contract])
+        L.ref_nn_build_info.restype = C.c_char_p
+        L.findNearestPointIdxLauncher.restype = None
+        L.findNearestPointIdxLauncher.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5
+        _nn_libs[contract] = L
+    ref = np.ascontiguousarray(ref_pts[None], np.float32)
+    que = np.ascontiguousarray(que_pts[None], np.float32)
+    idxs = np.zeros((1, que.shape[1]), np.int32)
+    _nn_libs[contract].findNearestPointIdxLauncher(ref.ctypes.data, que.ctypes.data, idxs.ctypes.data, 1, ref.shape[1],
+                                                   que.shape[1], ref.shape[2], 1 if exclude_self else 0)
+    return idxs[0]

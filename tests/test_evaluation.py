@@ -153,3 +153,32 @@ def test_add_s_and_symmetric_projection_for_a_symmetric_object():
     ev.evaluate(pts2d, pose, "eggbox")  # symmetric class: ADD-S -> correct
     ev.evaluate(pts2d, pose, "cat")     # ordinary class: ADD -> wrong
     assert ev.add_recorder == [True, False]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pn1,pn2,dim", [(5000, 7000, 3), (4097, 300, 2), (1, 9, 3), (20000, 64, 3)])
+def test_pinned_by_the_references_own_kernels(pn1, pn2, dim):
+    """oracle/_ref/libpvnet_refnn*.so = the reference's nearest_neighborhood.cu compiled for gfx950 from the reference
+    tree (`make -C oracle ref`), called through ITS OWN launcher: the numpy oracle and the product must return the very
+    indices the reference's device code returns (ties included); the FMA-contracted build (what nvcc's default allows)
+    may differ only where two candidates are within float32 rounding of each other."""
+    from oracle import refkernels
+    if not refkernels.nn_available("off"):
+        pytest.skip("oracle/_ref/libpvnet_refnn.so not built (needs the reference tree at build time)")
+    ref, que = clouds(pn1, pn2, dim, 31 + pn1, dup=min(20, pn1 // 2, pn2))
+    want = refkernels.find_nearest_point_idx(ref, que)
+    np.testing.assert_array_equal(nn_oracle.find_nearest_point_idx(ref, que), want)
+    got = E.nearest_point_idx(torch.from_numpy(ref).to(dev()), torch.from_numpy(que).to(dev())).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    if pn1 > 1:
+        ex = refkernels.find_nearest_point_idx(ref, ref, exclude_self=True)
+        np.testing.assert_array_equal(
+            E.nearest_point_idx(torch.from_numpy(ref).to(dev()), torch.from_numpy(ref).to(dev()), exclude_self=True).cpu().numpy(), ex)
+    if refkernels.nn_available("fast"):
+        fma = refkernels.find_nearest_point_idx(ref, que, contract="fast")
+        diff = fma != want
+        if diff.any():  # a different pick is only ever an equally near point (within float32 rounding)
+            d_a = np.linalg.norm(ref[fma[diff]].astype(np.float64) - que[diff], axis=1)
+            d_b = np.linalg.norm(ref[want[diff]].astype(np.float64) - que[diff], axis=1)
+            assert np.abs(d_a - d_b).max() <= 1e-6 * max(1.0, d_b.max())
+        assert diff.mean() < 0.01
