@@ -47,6 +47,14 @@ extern "C" {
                                       kernels.  Default: |d x u| < tan(acos(thresh)) * (d . u) evaluated as two
                                       bf16x3 MFMAs + compare (pvnet_vote.hip: score_mfma_kernel), fp32-equivalent */
 #define PVNET_F_NO_REFINE 2u       /* skip ransac_voting_gpu.py:579-595, return the winning hypotheses */
+/* element type of `vertex` (and, for pvnet_vote_v3_logits, of `seg_pred`) when it is not float32 -- what a backbone under
+ * autocast emits.  The pointer is passed through the `const float*` parameter and read as the flagged type; strides stay
+ * in ELEMENTS.  Elements are widened to float32 where they are read (exact), so the result equals the float32 path on
+ * `tensor.float()` without the copy.  At most one flag per tensor. */
+#define PVNET_F_VERTEX_F16   4u
+#define PVNET_F_VERTEX_BF16  8u
+#define PVNET_F_LOGITS_F16  16u
+#define PVNET_F_LOGITS_BF16 32u
 
 /* per-(image,key-point) status bits written to out_status */
 #define PVNET_S_SKIPPED   1        /* fewer than min_num foreground pixels (or none kept): zeros returned */

@@ -82,7 +82,8 @@ struct VoteParams {
     const void* mask;
     int64_t ms0, ms1, ms2, ms_c;
     int mask_dtype, mask_linear, num_classes;
-    const float* vertex;
+    int vertex_type, logits_type;  // VT_* of the field / of the class logits
+    const float* vertex;           // (typed by vertex_type)
     int64_t vs0, vs1, vs2, vs3, vs4;
     int b, h, w, vn, hn, npix, words, cap, chunk, max_chunks, hpl, hgroups, hn_pad, wg_g, wg_s, mode, score_xcd, atomic_counts;
     float thresh, tau;
@@ -251,6 +252,20 @@ __device__ __forceinline__ unsigned long long wave_reduce_max(unsigned long long
     return v;
 }
 
+// The vector field (and the class logits of the fused arg-max entry) may be float32, float16 or bfloat16 -- what a
+// backbone under autocast emits: elements are widened to float32 where they are read (both conversions are exact), so the
+// result is that of the float32 path on `field.float()` without the copy (786 MB written per batch of 32 otherwise).
+enum { VT_F32 = 0, VT_F16 = 1, VT_BF16 = 2 };
+template <int VT>
+__device__ __forceinline__ float ld_elem(const void* base, int64_t off) {
+    if (VT == VT_F16) return (float)reinterpret_cast<const _Float16*>(base)[off];
+    if (VT == VT_BF16) return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(base)[off] << 16);
+    return reinterpret_cast<const float*>(base)[off];
+}
+__device__ __forceinline__ float ld_elem_rt(int vt, const void* base, int64_t off) {  // run-time type (cold paths)
+    return vt == VT_F16 ? ld_elem<VT_F16>(base, off) : vt == VT_BF16 ? ld_elem<VT_BF16>(base, off) : ld_elem<VT_F32>(base, off);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // K1: mask -> bit mask + foreground count                     (ransac_voting_gpu.py:527-528)
 // ------------------------------------------------------------------------------------------------------------
@@ -285,11 +300,10 @@ __global__ __launch_bounds__(64 * K1_WAVES) void mask_bits_kernel(VoteParams P) 
                 off = (int64_t)bi * P.ms0 + (int64_t)y * P.ms1 + (int64_t)x * P.ms2;
             }
             if (DT == PVNET_MASK_LOGITS_F32) {  // fused torch.argmax(seg_pred, 1) (tools/demo.py:52): first maximum wins
-                const float* sp = reinterpret_cast<const float*>(P.mask) + off;
-                float best = sp[0];
+                float best = ld_elem_rt(P.logits_type, P.mask, off);
                 int arg = 0;
                 for (int c = 1; c < P.num_classes; ++c) {
-                    const float x = sp[(int64_t)c * P.ms_c];
+                    const float x = ld_elem_rt(P.logits_type, P.mask, off + (int64_t)c * P.ms_c);
                     if (x > best) { best = x; arg = c; }
                 }
                 v = (arg & 0xFF) != 0;  // then .byte() != 0 (ransac_voting_gpu.py:527)
@@ -364,7 +378,7 @@ __global__ __launch_bounds__(64 * K1B_WAVES) void subsample_kernel(VoteParams P)
 // ------------------------------------------------------------------------------------------------------------
 // K2: order-preserving compaction + direction gather          (ransac_voting_gpu.py:542-546)
 // ------------------------------------------------------------------------------------------------------------
-template <bool LITERAL, int K2_KG>  // K2_KG key-points per block: grid.z = ceil(vn / K2_KG)
+template <bool LITERAL, int K2_KG, int VT>  // K2_KG key-points per block: grid.z = ceil(vn / K2_KG); VT: field element type
 __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
     small_stage_prio();
     const int bi = blockIdx.y;
@@ -372,10 +386,14 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint64_t* bw = P.bits + (size_t)bi * P.words;
 
-    __shared__ int s_red[4];
-    __shared__ int s_woff[K2_WORDS_PER_BLOCK];
-    __shared__ uint64_t s_word[K2_WORDS_PER_BLOCK];
-    __shared__ int s_total;
+    // volatile: with plain LDS arrays one build of the <false, 1> instantiation (hipcc 7.2, gfx950) returned, in ~40 % of
+    // the runs, one wave's 64 records from pixels two ranks further on -- the word offsets of a neighbouring segment, i.e.
+    // LDS contents from before this workgroup's barrier; the same source compiled a commit earlier never did (0 / 400).
+    // Forcing every access to be performed as written removes it (0 / 600, tools/rep_flake3.py) at no measurable cost.
+    __shared__ volatile int s_red[4];
+    __shared__ volatile int s_woff[K2_WORDS_PER_BLOCK];
+    __shared__ volatile uint64_t s_word[K2_WORDS_PER_BLOCK];
+    __shared__ volatile int s_total;
 
     // pixels kept before this block = sum of the earlier segments' counts (<= a few hundred ints)
     const int32_t* sg = P.seg + bi * P.nseg;
@@ -445,16 +463,16 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
         if (has1) locate(t1, pos1, p1);
         const int y0 = p0 / P.w, x0 = p0 - y0 * P.w;
         const int y1 = p1 / P.w, x1 = p1 - y1 * P.w;
-        const float* v0 = P.vertex + (int64_t)bi * P.vs0 + (int64_t)y0 * P.vs1 + (int64_t)x0 * P.vs2;
-        const float* v1 = P.vertex + (int64_t)bi * P.vs0 + (int64_t)y1 * P.vs1 + (int64_t)x1 * P.vs2;
+        const int64_t v0 = (int64_t)bi * P.vs0 + (int64_t)y0 * P.vs1 + (int64_t)x0 * P.vs2;  // element offsets
+        const int64_t v1 = (int64_t)bi * P.vs0 + (int64_t)y1 * P.vs1 + (int64_t)x1 * P.vs2;
         float ux0[K2_KG], uy0[K2_KG], ux1[K2_KG], uy1[K2_KG];
 #pragma unroll
         for (int kk = 0; kk < K2_KG; ++kk) {
             const int k = (k0 + kk < P.vn) ? k0 + kk : P.vn - 1;  // clamp: loads stay in bounds, unconditional
-            ux0[kk] = v0[(int64_t)k * P.vs3];
-            uy0[kk] = v0[(int64_t)k * P.vs3 + P.vs4];
-            ux1[kk] = v1[(int64_t)k * P.vs3];  // (p1 = 0 when there is no second pixel: a valid address)
-            uy1[kk] = v1[(int64_t)k * P.vs3 + P.vs4];
+            ux0[kk] = ld_elem<VT>(P.vertex, v0 + (int64_t)k * P.vs3);
+            uy0[kk] = ld_elem<VT>(P.vertex, v0 + (int64_t)k * P.vs3 + P.vs4);
+            ux1[kk] = ld_elem<VT>(P.vertex, v1 + (int64_t)k * P.vs3);  // (p1 = 0 when there is no second pixel: a valid address)
+            uy1[kk] = ld_elem<VT>(P.vertex, v1 + (int64_t)k * P.vs3 + P.vs4);
         }
         if (pos0 < usable) {
             if (k0 == 0) P.pix[(size_t)bi * P.cap + pos0] = p0;
@@ -1129,9 +1147,9 @@ __global__ __launch_bounds__(256) void motion_partial_kernel(VoteParams P, doubl
             if (!((my >> i) & 1ull)) continue;
             const int p = ((sgi * 4 + wave) * WPW + i) * 64 + lane;
             const int y = p / P.w, x = p - y * P.w;
-            const float* v = P.vertex + (int64_t)bi * P.vs0 + (int64_t)y * P.vs1 + (int64_t)x * P.vs2 + (int64_t)k * P.vs3;
-            sx += (double)(v[0] + (float)x);      // the reference adds in float32 (:975), then averages
-            sy += (double)(v[P.vs4] + (float)y);
+            const int64_t v = (int64_t)bi * P.vs0 + (int64_t)y * P.vs1 + (int64_t)x * P.vs2 + (int64_t)k * P.vs3;
+            sx += (double)(ld_elem_rt(P.vertex_type, P.vertex, v) + (float)x);      // the reference adds in float32 (:975), then averages
+            sy += (double)(ld_elem_rt(P.vertex_type, P.vertex, v + P.vs4) + (float)y);
         }
         sx = wave_reduce_add(sx);
         sy = wave_reduce_add(sy);
@@ -1321,10 +1339,18 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
     if (stages & 4) {   // K2
         const int kg = T.compact_kg;
         dim3 grid(P.nseg, P.b, (P.vn + kg - 1) / kg);
-        if (literal) hipLaunchKernelGGL((compact_kernel<true, 3>), dim3(P.nseg, P.b, (P.vn + 2) / 3), dim3(256), 0, s, P);
-        else if (kg == 1) hipLaunchKernelGGL((compact_kernel<false, 1>), grid, dim3(256), 0, s, P);
-        else if (kg == 9) hipLaunchKernelGGL((compact_kernel<false, 9>), grid, dim3(256), 0, s, P);
-        else hipLaunchKernelGGL((compact_kernel<false, 3>), dim3(P.nseg, P.b, (P.vn + 2) / 3), dim3(256), 0, s, P);
+        const dim3 g3(P.nseg, P.b, (P.vn + 2) / 3);
+#define PV_K2(VT)                                                                                                  \
+    do {                                                                                                           \
+        if (literal) hipLaunchKernelGGL((compact_kernel<true, 3, VT>), g3, dim3(256), 0, s, P);                    \
+        else if (kg == 1) hipLaunchKernelGGL((compact_kernel<false, 1, VT>), grid, dim3(256), 0, s, P);            \
+        else if (kg == 9) hipLaunchKernelGGL((compact_kernel<false, 9, VT>), grid, dim3(256), 0, s, P);            \
+        else hipLaunchKernelGGL((compact_kernel<false, 3, VT>), g3, dim3(256), 0, s, P);                           \
+    } while (0)
+        if (P.vertex_type == VT_F16) PV_K2(VT_F16);
+        else if (P.vertex_type == VT_BF16) PV_K2(VT_BF16);
+        else PV_K2(VT_F32);
+#undef PV_K2
         PV_LAUNCH_CHECK();
     }
     PV_HIP(mark(3));
@@ -1401,6 +1427,10 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     P.mask_dtype = mask_dtype;
     P.mask_linear = (ms[2] == 1 && ms[1] == w) ? 1 : 0;
     P.vertex = vertex; P.vs0 = vs[0]; P.vs1 = vs[1]; P.vs2 = vs[2]; P.vs3 = vs[3]; P.vs4 = vs[4];
+    if ((flags & PVNET_F_VERTEX_F16) && (flags & PVNET_F_VERTEX_BF16)) return PVNET_E_BADARG;
+    if ((flags & PVNET_F_LOGITS_F16) && (flags & PVNET_F_LOGITS_BF16)) return PVNET_E_BADARG;
+    P.vertex_type = (flags & PVNET_F_VERTEX_F16) ? VT_F16 : (flags & PVNET_F_VERTEX_BF16) ? VT_BF16 : VT_F32;
+    P.logits_type = (flags & PVNET_F_LOGITS_F16) ? VT_F16 : (flags & PVNET_F_LOGITS_BF16) ? VT_BF16 : VT_F32;
     P.b = b; P.h = h; P.w = w; P.vn = vn; P.hn = hn; P.npix = h * w;
     P.words = L.words; P.cap = L.cap; P.chunk = L.chunk; P.max_chunks = L.max_chunks;
     P.hpl = L.hpl; P.hgroups = L.hgroups; P.hn_pad = L.hn_pad; P.wg_g = L.wg_g; P.wg_s = L.wg_s;

@@ -25,6 +25,7 @@ LIB_PATH = os.path.join(_HERE, "libpvnet_vote.so")
 
 F_LITERAL = 1
 F_NO_REFINE = 2
+F_VERTEX_F16, F_VERTEX_BF16, F_LOGITS_F16, F_LOGITS_BF16 = 4, 8, 16, 32
 S_SKIPPED, S_SINGULAR, S_NO_INLIER, S_OVERFLOW = 1, 2, 4, 8
 NUM_STAGES = 6
 STAGE_NAMES = ("mask_bits", "subsample", "compact", "hypotheses", "score", "select_refine")
@@ -105,6 +106,8 @@ def _check(rc: int, what: str):
     raise RuntimeError(f"{what} failed: {names.get(rc, 'hipError_t ' + str(rc))}")
 
 
+_FIELD_FLAGS = {torch.float32: 0, torch.float16: F_VERTEX_F16, torch.bfloat16: F_VERTEX_BF16}
+_LOGITS_FLAGS = {torch.float32: 0, torch.float16: F_LOGITS_F16, torch.bfloat16: F_LOGITS_BF16}
 _MASK_CODES = {torch.uint8: 0, torch.int8: 0, torch.bool: 0, torch.int16: 1, torch.int32: 2, torch.int64: 3,
                torch.float32: 4}
 
@@ -115,7 +118,7 @@ def vote_layout(b, h, w, vn, hn, max_num) -> Layout:
     return L
 
 
-def _prepare(mask, vertex, round_hyp_num, max_num, idxs):
+def _prepare(mask, vertex, round_hyp_num, max_num, idxs, convert_mask=True):
     if not (isinstance(mask, torch.Tensor) and isinstance(vertex, torch.Tensor)):
         raise TypeError("mask and vertex must be torch tensors")
     if not vertex.is_cuda:
@@ -129,9 +132,9 @@ def _prepare(mask, vertex, round_hyp_num, max_num, idxs):
     b, h, w, vn, _ = vertex.shape
     if tuple(mask.shape) != (b, h, w):
         raise RuntimeError(f"mask must be [b,h,w]={(b, h, w)}, got {tuple(mask.shape)}")
-    if vertex.dtype != torch.float32:
+    if vertex.dtype not in _FIELD_FLAGS:  # float32 / float16 / bfloat16 are read in place (autocast backbones emit the latter)
         vertex = vertex.float()
-    if mask.dtype not in _MASK_CODES:
+    if convert_mask and mask.dtype not in _MASK_CODES:
         mask = mask.float()  # .byte() of any other float type truncates the same way
     hn = int(round_hyp_num)
     if hn <= 0:
@@ -235,7 +238,7 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
     if seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     literal = effective_literal(literal, inlier_thresh)
-    flags = (F_LITERAL if literal else 0) | (0 if refine else F_NO_REFINE)
+    flags = (F_LITERAL if literal else 0) | (0 if refine else F_NO_REFINE) | _FIELD_FLAGS[vertex.dtype]
     L = vote_layout(b, h, w, vn, hn, max_num)
     with torch.cuda.device(dev):
         ws = _workspace(workspace, L, dev)
@@ -282,7 +285,7 @@ def stage_repeat_ms(mask, vertex, round_hyp_num, inlier_thresh=0.999, min_num=5,
     lib = load_library()
     mask, vertex, b, h, w, vn, hn, max_num, _ = _prepare(mask, vertex, round_hyp_num, max_num, None)
     dev = vertex.device
-    flags = F_LITERAL if effective_literal(literal, inlier_thresh) else 0
+    flags = (F_LITERAL if effective_literal(literal, inlier_thresh) else 0) | _FIELD_FLAGS[vertex.dtype]
     L = vote_layout(b, h, w, vn, hn, max_num)
     with torch.cuda.device(dev):
         ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=dev)
@@ -319,7 +322,7 @@ class VotePlan:
         self.dev = vertex.device
         self.layout = vote_layout(b, h, w, vn, hn, max_num)
         self.literal = effective_literal(literal, inlier_thresh)
-        flags = (F_LITERAL if self.literal else 0) | (0 if refine else F_NO_REFINE)
+        flags = (F_LITERAL if self.literal else 0) | (0 if refine else F_NO_REFINE) | _FIELD_FLAGS[vertex.dtype]
         with torch.cuda.device(self.dev):
             self.workspace = torch.empty(self.layout.total_bytes, dtype=torch.uint8, device=self.dev)
             self.out = torch.empty((b, vn, 2), dtype=torch.float32, device=self.dev)
@@ -356,15 +359,17 @@ def ransac_voting_layer_v3_from_logits(seg_pred, vertex, round_hyp_num, inlier_t
     lib = load_library()
     if not seg_pred.is_cuda or seg_pred.dim() != 4:
         raise RuntimeError("seg_pred must be a CUDA tensor [b,C,h,w]")
-    if seg_pred.dtype != torch.float32:
+    if seg_pred.dtype not in _LOGITS_FLAGS:
         seg_pred = seg_pred.float()
     b, nc, h, w = seg_pred.shape
     fake_mask = seg_pred[:, 0]  # shape/device checks only
-    _, vertex, b, h, w, vn, hn, max_num, idxs = _prepare(fake_mask, vertex, round_hyp_num, max_num, idxs)
+    _, vertex, b, h, w, vn, hn, max_num, idxs = _prepare(fake_mask, vertex, round_hyp_num, max_num, idxs,
+                                                         convert_mask=False)
     dev = vertex.device
     if seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-    flags = (F_LITERAL if effective_literal(literal, inlier_thresh) else 0) | (0 if refine else F_NO_REFINE)
+    flags = (F_LITERAL if effective_literal(literal, inlier_thresh) else 0) | (0 if refine else F_NO_REFINE) | \
+        _FIELD_FLAGS[vertex.dtype] | _LOGITS_FLAGS[seg_pred.dtype]
     L = vote_layout(b, h, w, vn, hn, max_num)
     with torch.cuda.device(dev):
         ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=dev)
@@ -459,6 +464,8 @@ def ransac_motion_voting(mask, vertex):
     vectors of the (strided) field are read and summed in float64 (``pvnet_motion_voting``)."""
     lib = load_library()
     mask, vertex, b, h, w, vn, _, _, _ = _prepare(mask, vertex, 1, 0, None)
+    if vertex.dtype != torch.float32:
+        vertex = vertex.float()  # (this entry point takes float32 fields only)
     dev = vertex.device
     with torch.cuda.device(dev):
         nbytes = lib.pvnet_motion_workspace_bytes(b, h, w, vn)

@@ -276,3 +276,54 @@ def test_vote_plan_matches_the_plain_call():
         voting.ransac_voting_layer_v3(m, v, 512, inlier_thresh=0.99, seed=2, workspace=ws[:1000])
     with pytest.raises(RuntimeError, match="VotePlan"):
         plan(m[:, :100], v[:, :100])
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_half_precision_fields_and_logits_are_read_in_place(dt):
+    """a backbone under autocast emits bf16 / fp16: the field (and the class logits of the fused arg-max entry) are
+    widened where they are read -- bit-identical to the float32 path on `.float()`, without the 786 MB copy"""
+    mask, planar, _ = synth.make_batch(3, first_index=8100, h=120, w=160, radius=18, noise=True, background="normal")
+    m = torch.from_numpy(mask).to(dev())
+    p16 = torch.from_numpy(planar).to(dev()).to(dt)
+    v16 = synth.planar_to_vertex_view(p16)
+    v32 = synth.planar_to_vertex_view(p16.float())
+    assert v16.dtype == dt and not v16.is_contiguous()
+    for literal in (False, True):
+        ref, dr = voting.ransac_voting_layer_v3(m, v32, 256, inlier_thresh=0.99, seed=3, literal=literal, return_debug=True)
+        ref, cr = ref.clone(), dr["counts"].clone()
+        out, do = voting.ransac_voting_layer_v3(m, v16, 256, inlier_thresh=0.99, seed=3, literal=literal, return_debug=True)
+        assert torch.equal(out, ref) and torch.equal(do["counts"], cr)
+    seg = torch.stack([1.0 - m.float(), m.float()], 1).contiguous()
+    seg = (seg + 0.05 * torch.randn(seg.shape, device=dev())).to(dt)
+    a = voting.ransac_voting_layer_v3(torch.argmax(seg.float(), 1), v32, 256, inlier_thresh=0.99, seed=4)
+    b = voting.ransac_voting_layer_v3_from_logits(seg, v16, 256, inlier_thresh=0.99, seed=4)
+    assert torch.equal(a, b)
+    plan = voting.VotePlan(m, v16, 256, inlier_thresh=0.99)
+    assert torch.equal(plan(m, v16, seed=3), ref if False else voting.ransac_voting_layer_v3(m, v32, 256, inlier_thresh=0.99, seed=3))
+    mo = voting.ransac_motion_voting(m, v16)
+    assert torch.equal(mo, voting.ransac_motion_voting(m, v32))
+
+
+@pytest.mark.parametrize("kg", ["1", "3", "9"])
+def test_compaction_is_deterministic_for_every_tiling(kg, monkeypatch):
+    """regression: one build of compact_kernel<false, 1> returned, in ~40 % of the runs, one wave's 64 records from pixels
+    two ranks further on (LDS word offsets read as a neighbouring segment left them); the LDS arrays of K2 are volatile
+    since.  80 repeated calls per tiling must reproduce the records, hypotheses and counts of the first bit for bit."""
+    mask, planar, _ = synth.make_batch(3, first_index=1300, h=200, w=280, radius=31, noise=True, background="normal")
+    m, v = to_dev(mask, planar)
+    monkeypatch.setenv("PVNET_COMPACT_KG", "3")
+    voting.reload_tuning()
+    try:
+        _, d = voting.ransac_voting_layer_v3(m, v, 700, inlier_thresh=0.99, seed=9, return_debug=True)
+        tn = [int(x) for x in d["tn"]]
+        ref = (d["rec"].clone(), d["hyp"].clone(), d["counts"].clone())
+        monkeypatch.setenv("PVNET_COMPACT_KG", kg)
+        voting.reload_tuning()
+        for rep in range(80):
+            _, g = voting.ransac_voting_layer_v3(m, v, 700, inlier_thresh=0.99, seed=9, return_debug=True)
+            for bi in range(3):
+                assert torch.equal(g["rec"][bi, :, :tn[bi]], ref[0][bi, :, :tn[bi]]), (kg, rep, bi)
+            assert torch.equal(g["hyp"], ref[1]) and torch.equal(g["counts"], ref[2]), (kg, rep)
+    finally:
+        monkeypatch.delenv("PVNET_COMPACT_KG")
+        voting.reload_tuning()
