@@ -7,7 +7,9 @@
  *   - pvnet_generate_hypothesis()     replaces the pybind op `generate_hypothesis`
  *                                     (src/ransac_voting.cpp:20-31 -> src/ransac_voting_kernel.cu:51-86);
  *   - pvnet_voting_for_hypothesis()   replaces the pybind op `voting_for_hypothesis`
- *                                     (src/ransac_voting.cpp:41-55 -> src/ransac_voting_kernel.cu:129-167).
+ *                                     (src/ransac_voting.cpp:41-55 -> src/ransac_voting_kernel.cu:129-167);
+ *   - pvnet_generate_hypothesis_vanishing_point() / pvnet_voting_for_hypothesis_vanishing_point()
+ *                                     replace the other two pybind ops of the extension (src/ransac_voting.cpp:57-99).
  * Plain pointers and sizes only (no torch types).  All pointers are DEVICE pointers unless marked host.
  * Every entry point only enqueues work on `stream` (a hipStream_t passed as void*): no allocation, no
  * host synchronisation, no global state -- re-entrant and hipGraph-capturable.  (pvnet_vote_v3_profiled is the
@@ -26,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PVNET_VOTE_ABI_VERSION 3
+#define PVNET_VOTE_ABI_VERSION 4
 
 /* negative library error codes */
 #define PVNET_E_BADARG      (-1)   /* null pointer / non-positive size / unsupported dtype or stride */
@@ -199,6 +201,17 @@ int pvnet_generate_hypothesis(const float* direct, const float* coords, const in
  * untouched (ransac_voting_kernel.cu:124-125).  Float32 operation order of the reference (literal mode). */
 int pvnet_voting_for_hypothesis(const float* direct, const float* coords, const float* hypo_pts, uint8_t* inliers,
                                 int tn, int vn, int hn, float inlier_thresh, void* stream);
+
+/* The vanishing-point pair of the reference's extension (src/ransac_voting.cpp:57-99 ->
+ * src/ransac_voting_kernel.cu:170-266, :268-351): hypo_pts [hn,vn,3] are homogeneous points (x, y, z), the cross
+ * product of the two pixels' line coordinates (z = 0: the rays are parallel; (0,0,0): they do not meet); a pixel votes
+ * when |cos angle(direct, h.xy - c * h.z)| > inlier_thresh and both component products are non-negative.  Same layouts,
+ * in/out convention and float32 operation order as the two ops above. */
+int pvnet_generate_hypothesis_vanishing_point(const float* direct, const float* coords, const int32_t* idxs,
+                                              float* hypo_pts, int tn, int vn, int hn, void* stream);
+int pvnet_voting_for_hypothesis_vanishing_point(const float* direct, const float* coords, const float* hypo_pts,
+                                                uint8_t* inliers, int tn, int vn, int hn, float inlier_thresh,
+                                                void* stream);
 
 /* ABI / build identification (host-only) */
 int pvnet_vote_abi_version(void);

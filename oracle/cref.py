@@ -69,6 +69,29 @@ def voting_for_hypothesis(direct, coords, hyp, inliers, thresh):
     return inliers
 
 
+def generate_hypothesis_vanishing_point(direct, coords, idxs):
+    direct = np.ascontiguousarray(direct, np.float32)
+    coords = np.ascontiguousarray(coords, np.float32)
+    idxs = np.ascontiguousarray(idxs, np.int32)
+    tn, vn, _ = direct.shape
+    hn = idxs.shape[0]
+    hyp = np.zeros((hn, vn, 3), np.float32)
+    lib().ref_generate_hypothesis_vanishing_point(_p(direct, C.c_float), _p(coords, C.c_float), _p(idxs, C.c_int32),
+                                                  _p(hyp, C.c_float), tn, vn, hn)
+    return hyp
+
+
+def voting_for_hypothesis_vanishing_point(direct, coords, hyp, inliers, thresh):
+    direct = np.ascontiguousarray(direct, np.float32)
+    coords = np.ascontiguousarray(coords, np.float32)
+    hyp = np.ascontiguousarray(hyp, np.float32)
+    assert inliers.dtype == np.uint8 and inliers.flags.c_contiguous and hyp.shape[2] == 3
+    tn, vn, _ = direct.shape
+    lib().ref_voting_for_hypothesis_vanishing_point(_p(direct, C.c_float), _p(coords, C.c_float), _p(hyp, C.c_float),
+                                                    _p(inliers, C.c_uint8), tn, vn, hyp.shape[0], C.c_float(thresh))
+    return inliers
+
+
 def vote_v3(fg, vertex, hn, thresh=0.999, min_num=5, max_num=30000, seed=0, idxs=None, return_winners=False,
             image_base=0):
     """fg [b,h,w] bool/uint8, vertex [b,h,w,vn,2] float32 with ANY strides (multiples of 4 bytes); image_base = global

@@ -6,6 +6,7 @@
  * Follows, line by line in float32 with ONE rounding per operation (build with -ffp-contract=off):
  *   lib/ransac_voting_gpu_layer/src/ransac_voting_kernel.cu:11-49    generate_hypothesis_kernel
  *   lib/ransac_voting_gpu_layer/src/ransac_voting_kernel.cu:88-126   voting_for_hypothesis_kernel
+ *   lib/ransac_voting_gpu_layer/src/ransac_voting_kernel.cu:170-229, :268-310   the vanishing-point pair of the two
  *   lib/ransac_voting_gpu_layer/ransac_voting_gpu.py:514-598         ransac_voting_layer_v3 (one round; the
  *        reference's later rounds re-use the same idxs (:547 vs :552) and cannot change the result)
  *   lib/ransac_voting_gpu_layer/ransac_voting_gpu.py:503-512         b_inv (2x2)
@@ -106,6 +107,55 @@ void ref_voting_for_hypothesis(const float* direct, const float* coords, const f
             if (inlier_one(coords[ti * 2], coords[ti * 2 + 1], direct[ti * vn * 2 + vi * 2],
                            direct[ti * vn * 2 + vi * 2 + 1], hx, hy, thresh))
                 row[ti] = 1;
+    }
+}
+
+/* ransac_voting_kernel.cu:170-229 generate_hypothesis_vanishing_point_kernel: direct [tn,vn,2], coords [tn,2],
+ * idxs [hn,vn,2] -> hyp [hn,vn,3] homogeneous (x, y, z) */
+void ref_generate_hypothesis_vanishing_point(const float* direct, const float* coords, const int32_t* idxs, float* hyp,
+                                             int tn, int vn, int hn) {
+    (void)tn;
+    for (int hvi = 0; hvi < hn * vn; ++hvi) {
+        int hi = hvi / vn, vi = hvi - hi * vn;
+        int id0 = idxs[hvi * 2], id1 = idxs[hvi * 2 + 1];
+        float dx0 = direct[id0 * vn * 2 + vi * 2], dy0 = direct[id0 * vn * 2 + vi * 2 + 1];       /* :192-195 */
+        float cx0 = coords[id0 * 2], cy0 = coords[id0 * 2 + 1];
+        float dx1 = direct[id1 * vn * 2 + vi * 2], dy1 = direct[id1 * vn * 2 + vi * 2 + 1];       /* :197-200 */
+        float cx1 = coords[id1 * 2], cy1 = coords[id1 * 2 + 1];
+        float lx0 = dy0, ly0 = -dx0, lz0 = cy0 * dx0 - cx0 * dy0;                                 /* :202-204 */
+        float lx1 = dy1, ly1 = -dx1, lz1 = cy1 * dx1 - cx1 * dy1;                                 /* :206-208 */
+        float x = ly0 * lz1 - lz0 * ly1;                                                          /* :211-213 */
+        float y = lz0 * lx1 - lx0 * lz1;
+        float z = lx0 * ly1 - ly0 * lx1;
+        float val_x0 = dx0 * (x - z * cx0), val_x1 = dx1 * (x - z * cx1);                         /* :216-219 */
+        float val_y0 = dy0 * (y - z * cy0), val_y1 = dy1 * (y - z * cy1);
+        if (val_x0 < 0 && val_x1 < 0 && val_y0 < 0 && val_y1 < 0) { z = -z; x = -x; y = -y; }     /* :221-222 */
+        if (val_x0 * val_x1 < 0 || val_y0 * val_y1 < 0) { x = 0.f; y = 0.f; z = 0.f; }            /* :224-225 */
+        hyp[hvi * 3] = x; hyp[hvi * 3 + 1] = y; hyp[hvi * 3 + 2] = z;
+    }
+}
+
+/* ransac_voting_kernel.cu:268-310 voting_for_hypothesis_vanishing_point_kernel: hyp [hn,vn,3]; sets 1s in
+ * inliers [hn,vn,tn], never clears */
+void ref_voting_for_hypothesis_vanishing_point(const float* direct, const float* coords, const float* hyp,
+                                               uint8_t* inliers, int tn, int vn, int hn, float thresh) {
+#pragma omp parallel for schedule(static)
+    for (int hv = 0; hv < hn * vn; ++hv) {
+        int vi = hv % vn;
+        float hx = hyp[hv * 3], hy = hyp[hv * 3 + 1], hz = hyp[hv * 3 + 2];
+        uint8_t* row = inliers + (size_t)hv * tn;
+        for (int ti = 0; ti < tn; ++ti) {
+            float cx = coords[ti * 2], cy = coords[ti * 2 + 1];
+            float direct_x = direct[ti * vn * 2 + vi * 2], direct_y = direct[ti * vn * 2 + vi * 2 + 1];
+            float diff_x = hx - cx * hz, diff_y = hy - cy * hz;                                    /* :295-296 */
+            float norm1 = sqrtf(direct_x * direct_x + direct_y * direct_y);
+            float norm2 = sqrtf(diff_x * diff_x + diff_y * diff_y);
+            if ((double)norm1 < 1e-6 || (double)norm2 < 1e-6) continue;                            /* :300 */
+            float angle_dist = (direct_x * diff_x + direct_y * diff_y) / (norm1 * norm2);
+            float val_x = diff_x * direct_x, val_y = diff_y * direct_y;
+            if (val_x < 0 || val_y < 0) continue;                                                  /* :306 */
+            if (fabsf(angle_dist) > thresh) row[ti] = 1;                                           /* :307-308 */
+        }
     }
 }
 

@@ -178,6 +178,58 @@ def voting_for_hypothesis(direct, coords, hyp, thresh, dtype=np.float64, hyp_chu
     return out
 
 
+def generate_hypothesis_vanishing_point(direct, coords, idxs, dtype=np.float64):
+    """ransac_voting_kernel.cu:170-229.  direct [tn,vn,2], coords [tn,2], idxs [hn,vn,2] -> [hn,vn,3]: the homogeneous
+    intersection (x, y, z) of the two rays (cross product of their line coordinates), flipped when both rays point away
+    from it (:221-222), zeroed when the rays do not meet (:224-225)."""
+    T = dtype
+    vn = idxs.shape[1]
+    k = np.arange(vn)[None, :]
+    t0, t1 = idxs[..., 0], idxs[..., 1]
+    d0, d1 = direct[t0, k].astype(T), direct[t1, k].astype(T)
+    c0, c1 = coords[t0].astype(T), coords[t1].astype(T)
+    dx0, dy0, dx1, dy1 = d0[..., 0], d0[..., 1], d1[..., 0], d1[..., 1]
+    cx0, cy0, cx1, cy1 = c0[..., 0], c0[..., 1], c1[..., 0], c1[..., 1]
+    with np.errstate(over="ignore", invalid="ignore"):
+        lx0, ly0, lz0 = dy0, -dx0, cy0 * dx0 - cx0 * dy0  # :202-204
+        lx1, ly1, lz1 = dy1, -dx1, cy1 * dx1 - cx1 * dy1  # :206-208
+        x = ly0 * lz1 - lz0 * ly1  # :211-213
+        y = lz0 * lx1 - lx0 * lz1
+        z = lx0 * ly1 - ly0 * lx1
+        vx0, vx1 = dx0 * (x - z * cx0), dx1 * (x - z * cx1)  # :216-219
+        vy0, vy1 = dy0 * (y - z * cy0), dy1 * (y - z * cy1)
+        flip = (vx0 < 0) & (vx1 < 0) & (vy0 < 0) & (vy1 < 0)
+        miss = (vx0 * vx1 < 0) | (vy0 * vy1 < 0)
+    out = np.stack([x, y, z], axis=-1)
+    out = np.where(flip[..., None], -out, out)
+    out = np.where(miss[..., None], T(0), out)
+    return out.astype(T)
+
+
+def voting_for_hypothesis_vanishing_point(direct, coords, hyp, thresh, dtype=np.float64, hyp_chunk=64):
+    """ransac_voting_kernel.cu:268-310: inlier tensor [hn,vn,tn] uint8 for homogeneous hypotheses hyp [hn,vn,3]."""
+    T = dtype
+    hn, vn, _ = hyp.shape
+    tn = coords.shape[0]
+    out = np.zeros((hn, vn, tn), np.uint8)
+    cx, cy = coords[None, :, 0].astype(T), coords[None, :, 1].astype(T)
+    for k in range(vn):
+        ux, uy = direct[None, :, k, 0].astype(T), direct[None, :, k, 1].astype(T)
+        norm1 = np.sqrt(ux * ux + uy * uy)
+        for h0 in range(0, hn, hyp_chunk):
+            hp = hyp[h0:h0 + hyp_chunk, k].astype(T)
+            with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+                dx = hp[:, None, 0] - cx * hp[:, None, 2]  # :295-296
+                dy = hp[:, None, 1] - cy * hp[:, None, 2]
+                norm2 = np.sqrt(dx * dx + dy * dy)
+                valid = ~((norm1.astype(np.float64) < 1e-6) | (norm2.astype(np.float64) < 1e-6))  # :300
+                ang = (ux * dx + uy * dy) / (norm1 * norm2)
+                vx, vy = dx * ux, dy * uy
+                wrong = (vx < 0) | (vy < 0)  # :306
+                out[h0:h0 + hyp_chunk, k] = valid & ~wrong & (np.abs(ang) > T(np.float32(thresh)))
+    return out
+
+
 def voting_counts(direct, coords, hyp, thresh, dtype=np.float64, hyp_chunk=64):
     """``torch.sum(cur_inlier, 2)`` without materialising it (ransac_voting_gpu.py:557-561) -> [hn,vn] int64."""
     hn, vn, _ = hyp.shape

@@ -23,6 +23,22 @@ int ref_voting_for_hypothesis(const float* direct, const float* coords, const fl
                                    inlier_thresh);
     return (int)hipDeviceSynchronize();
 }
+// the vanishing-point pair (ransac_voting.cpp:57-99): hypo_pts [hn,vn,3]
+int ref_generate_hypothesis_vanishing_point(const float* direct, const float* coords, const int* idxs, float* hypo_pts,
+                                            int tn, int vn, int hn) {
+    at::Tensor out = generate_hypothesis_vanishing_point_launcher(
+        at::Tensor::wrap(direct, tn, vn, 2), at::Tensor::wrap(coords, tn, 2, 1), at::Tensor::wrap(idxs, hn, vn, 2));
+    hipError_t e = hipMemcpy(hypo_pts, out.data<float>(), sizeof(float) * (size_t)hn * vn * 3, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    return (int)e;
+}
+int ref_voting_for_hypothesis_vanishing_point(const float* direct, const float* coords, const float* hypo_pts,
+                                              unsigned char* inliers, int tn, int vn, int hn, float inlier_thresh) {
+    voting_for_hypothesis_vanishing_point_launcher(at::Tensor::wrap(direct, tn, vn, 2), at::Tensor::wrap(coords, tn, 2, 1),
+                                                   at::Tensor::wrap(hypo_pts, hn, vn, 3),
+                                                   at::Tensor::wrap(inliers, hn, vn, tn), inlier_thresh);
+    return (int)hipDeviceSynchronize();
+}
 const char* ref_build_info(void) {
 #ifdef PVNET_REF_CONTRACT
     return "reference kernels, gfx950, fp-contract=" PVNET_REF_CONTRACT;

@@ -1,5 +1,5 @@
 """ctypes binding of oracle/_ref/libpvnet_refkernels*.so -- the reference's OWN CUDA kernels
-(lib/ransac_voting_gpu_layer/src/ransac_voting_kernel.cu:11-126), compiled for gfx950 from the reference tree by
+(lib/ransac_voting_gpu_layer/src/ransac_voting_kernel.cu:11-351, all four kernels), compiled for gfx950 from the reference tree by
 `make -C oracle ref` through the header shim in oracle/ref_kernels/ -- TEST INFRASTRUCTURE.
 
 Only tests/ (GPU parity tests) and tools/ may import this; the product never does.  The libraries are built in the
@@ -38,6 +38,8 @@ def lib(contract: str = "off"):
         L.ref_build_info.restype = C.c_char_p
         L.ref_generate_hypothesis.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3
         L.ref_voting_for_hypothesis.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_float]
+        L.ref_generate_hypothesis_vanishing_point.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3
+        L.ref_voting_for_hypothesis_vanishing_point.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_float]
         _libs[contract] = L
     return _libs[contract]
 
@@ -72,6 +74,36 @@ def voting_for_hypothesis(direct, coords, hypo_pts, inlier_thresh, contract: str
     torch.cuda.synchronize()
     rc = lib(contract).ref_voting_for_hypothesis(direct.data_ptr(), coords.data_ptr(), hypo_pts.data_ptr(),
                                                  inl.data_ptr(), tn, vn, hn, float(inlier_thresh))
+    assert rc == 0, f"hip error {rc}"
+    return inl
+
+
+def generate_hypothesis_vanishing_point(direct, coords, idxs, contract: str = "off"):
+    """ransac_voting_kernel.cu:231-266 through its own launcher -> [hn,vn,3] f32."""
+    import torch
+    _check(direct, torch.float32); _check(coords, torch.float32); _check(idxs, torch.int32)
+    tn, vn, _ = direct.shape
+    hn = idxs.shape[0]
+    out = torch.empty((hn, vn, 3), dtype=torch.float32, device=direct.device)
+    torch.cuda.synchronize()
+    rc = lib(contract).ref_generate_hypothesis_vanishing_point(direct.data_ptr(), coords.data_ptr(), idxs.data_ptr(),
+                                                               out.data_ptr(), tn, vn, hn)
+    assert rc == 0, f"hip error {rc}"
+    return out
+
+
+def voting_for_hypothesis_vanishing_point(direct, coords, hypo_pts, inlier_thresh, contract: str = "off"):
+    """ransac_voting_kernel.cu:313-351 through its own launcher -> inliers [hn,vn,tn] uint8 (zero-initialised here)."""
+    import torch
+    _check(direct, torch.float32); _check(coords, torch.float32); _check(hypo_pts, torch.float32)
+    tn, vn, _ = direct.shape
+    hn = hypo_pts.shape[0]
+    assert hypo_pts.shape[2] == 3
+    inl = torch.zeros((hn, vn, tn), dtype=torch.uint8, device=direct.device)
+    torch.cuda.synchronize()
+    rc = lib(contract).ref_voting_for_hypothesis_vanishing_point(direct.data_ptr(), coords.data_ptr(),
+                                                                 hypo_pts.data_ptr(), inl.data_ptr(), tn, vn, hn,
+                                                                 float(inlier_thresh))
     assert rc == 0, f"hip error {rc}"
     return inl
 

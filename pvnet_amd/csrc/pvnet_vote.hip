@@ -1224,10 +1224,87 @@ __global__ __launch_bounds__(256) void op_voting_kernel(const float* __restrict_
     }
 }
 
+// The vanishing-point pair of the reference's extension (ransac_voting_kernel.cu:170-229, :268-310): hypotheses are
+// homogeneous points (x, y, z) -- the cross product of the two pixels' line coordinates, so that parallel rays give a
+// point at infinity (z = 0) instead of the (0, 0) of the affine op -- and a pixel votes when |cos| of the angle
+// between its direction and (h.xy - c * h.z) exceeds the threshold with both component products non-negative.
+// Float32 in the reference's operation order, one rounding per operation; the `< 1e-6` gates compare in double as the
+// reference's float-against-double-literal comparisons do.
+__global__ __launch_bounds__(256) void op_generate_hypothesis_vp_kernel(const float* __restrict__ direct,
+                                                                        const float* __restrict__ coords,
+                                                                        const int32_t* __restrict__ idxs,
+                                                                        float* __restrict__ hyp, int tn, int vn, int hn) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= hn * vn) return;
+    const int k = i % vn;
+    int t0 = idxs[i * 2], t1 = idxs[i * 2 + 1];
+    t0 = t0 < 0 ? 0 : (t0 >= tn ? tn - 1 : t0);
+    t1 = t1 < 0 ? 0 : (t1 >= tn ? tn - 1 : t1);
+    const float dx0 = direct[((size_t)t0 * vn + k) * 2], dy0 = direct[((size_t)t0 * vn + k) * 2 + 1];
+    const float dx1 = direct[((size_t)t1 * vn + k) * 2], dy1 = direct[((size_t)t1 * vn + k) * 2 + 1];
+    const float cx0 = coords[t0 * 2], cy0 = coords[t0 * 2 + 1], cx1 = coords[t1 * 2], cy1 = coords[t1 * 2 + 1];
+    const float lx0 = dy0, ly0 = -dx0, lz0 = cy0 * dx0 - cx0 * dy0;  // the line through c along d: l . (x, y, 1) = 0
+    const float lx1 = dy1, ly1 = -dx1, lz1 = cy1 * dx1 - cx1 * dy1;
+    float x = ly0 * lz1 - lz0 * ly1;
+    float y = lz0 * lx1 - lx0 * lz1;
+    float z = lx0 * ly1 - ly0 * lx1;
+    const float vx0 = dx0 * (x - z * cx0), vx1 = dx1 * (x - z * cx1);
+    const float vy0 = dy0 * (y - z * cy0), vy1 = dy1 * (y - z * cy1);
+    if (vx0 < 0 && vx1 < 0 && vy0 < 0 && vy1 < 0) {  // both rays point away from the intersection: flip the point
+        z = -z;
+        x = -x;
+        y = -y;
+    }
+    if (vx0 * vx1 < 0 || vy0 * vy1 < 0) x = y = z = 0.f;  // the rays do not meet
+    hyp[(size_t)i * 3] = x;
+    hyp[(size_t)i * 3 + 1] = y;
+    hyp[(size_t)i * 3 + 2] = z;
+}
+
+// same shape as op_voting_kernel: lane owns a pixel and walks a slice of hypotheses
+__global__ __launch_bounds__(256) void op_voting_vp_kernel(const float* __restrict__ direct,
+                                                           const float* __restrict__ coords,
+                                                           const float* __restrict__ hyp, uint8_t* __restrict__ inliers,
+                                                           int tn, int vn, int hn, float thresh, int hslice) {
+#pragma clang fp contract(off)
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    const int h0 = blockIdx.z * hslice;
+    const int h1 = h0 + hslice < hn ? h0 + hslice : hn;
+    if (t >= tn) return;
+    const float cx = coords[t * 2], cy = coords[t * 2 + 1];
+    const float ux = direct[((size_t)t * vn + k) * 2], uy = direct[((size_t)t * vn + k) * 2 + 1];
+    const float norm1 = __builtin_sqrtf(ux * ux + uy * uy);
+    if (norm1 < 1e-6) return;
+    for (int h = h0; h < h1; ++h) {
+        const float* hp = hyp + ((size_t)h * vn + k) * 3;
+        const float hx = hp[0], hy = hp[1], hz = hp[2];
+        const float dx = hx - cx * hz, dy = hy - cy * hz;
+        const float norm2 = __builtin_sqrtf(dx * dx + dy * dy);
+        if (norm2 < 1e-6) continue;
+        const float ang = (ux * dx + uy * dy) / (norm1 * norm2);
+        const float vx = dx * ux, vy = dy * uy;
+        if (vx < 0 || vy < 0) continue;  // the direction is wrong (:306)
+        if (fabsf(ang) > thresh) inliers[((size_t)h * vn + k) * tn + t] = 1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// the op-level voting kernels: hypotheses per z-slice so that the launch has >= 2048 workgroups
+inline void op_voting_grid(int tn, int vn, int hn, int* hslice, int* slices) {
+    const int tblocks = (tn + 255) / 256;
+    int n = (2048 + tblocks * vn - 1) / (tblocks * vn);
+    if (n > hn) n = hn;
+    if (n > 65535) n = 65535;
+    if (n < 1) n = 1;
+    *hslice = (hn + n - 1) / n;
+    *slices = (hn + *hslice - 1) / *hslice;
+}
 
 int env_int(const char* name, int dflt) {
     const char* s = getenv(name);
@@ -1755,15 +1832,34 @@ int pvnet_voting_for_hypothesis(const float* direct, const float* coords, const 
                                 int tn, int vn, int hn, float inlier_thresh, void* stream) {
     if (!direct || !coords || !hypo_pts || !inliers || tn <= 0 || vn <= 0 || hn <= 0) return PVNET_E_BADARG;
     if (vn > 65535) return PVNET_E_UNSUPPORTED;
-    const int tblocks = (tn + 255) / 256;
-    int slices = (2048 + tblocks * vn - 1) / (tblocks * vn);  // aim for >= 2048 blocks
-    if (slices > hn) slices = hn;
-    if (slices > 65535) slices = 65535;
-    if (slices < 1) slices = 1;
-    const int hslice = (hn + slices - 1) / slices;
-    slices = (hn + hslice - 1) / hslice;
-    hipLaunchKernelGGL(op_voting_kernel, dim3(tblocks, vn, slices), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       direct, coords, hypo_pts, inliers, tn, vn, hn, inlier_thresh, hslice);
+    int hslice, slices;
+    op_voting_grid(tn, vn, hn, &hslice, &slices);
+    hipLaunchKernelGGL(op_voting_kernel, dim3((tn + 255) / 256, vn, slices), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), direct, coords, hypo_pts, inliers, tn, vn, hn, inlier_thresh,
+                       hslice);
+    PV_LAUNCH_CHECK();
+    return 0;
+}
+
+int pvnet_generate_hypothesis_vanishing_point(const float* direct, const float* coords, const int32_t* idxs,
+                                              float* hypo_pts, int tn, int vn, int hn, void* stream) {
+    if (!direct || !coords || !idxs || !hypo_pts || tn <= 0 || vn <= 0 || hn <= 0) return PVNET_E_BADARG;
+    hipLaunchKernelGGL(op_generate_hypothesis_vp_kernel, dim3((hn * vn + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), direct, coords, idxs, hypo_pts, tn, vn, hn);
+    PV_LAUNCH_CHECK();
+    return 0;
+}
+
+int pvnet_voting_for_hypothesis_vanishing_point(const float* direct, const float* coords, const float* hypo_pts,
+                                                uint8_t* inliers, int tn, int vn, int hn, float inlier_thresh,
+                                                void* stream) {
+    if (!direct || !coords || !hypo_pts || !inliers || tn <= 0 || vn <= 0 || hn <= 0) return PVNET_E_BADARG;
+    if (vn > 65535) return PVNET_E_UNSUPPORTED;
+    int hslice, slices;
+    op_voting_grid(tn, vn, hn, &hslice, &slices);
+    hipLaunchKernelGGL(op_voting_vp_kernel, dim3((tn + 255) / 256, vn, slices), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), direct, coords, hypo_pts, inliers, tn, vn, hn, inlier_thresh,
+                       hslice);
     PV_LAUNCH_CHECK();
     return 0;
 }

@@ -76,6 +76,10 @@ def load_library() -> C.CDLL:
     lib.pvnet_voting_for_hypothesis.restype = C.c_int
     lib.pvnet_voting_for_hypothesis.argtypes = [f32p, f32p, f32p, u8p, C.c_int, C.c_int, C.c_int, C.c_float,
                                                 C.c_void_p]
+    lib.pvnet_generate_hypothesis_vanishing_point.restype = C.c_int
+    lib.pvnet_generate_hypothesis_vanishing_point.argtypes = lib.pvnet_generate_hypothesis.argtypes
+    lib.pvnet_voting_for_hypothesis_vanishing_point.restype = C.c_int
+    lib.pvnet_voting_for_hypothesis_vanishing_point.argtypes = lib.pvnet_voting_for_hypothesis.argtypes
     ws_tail = [C.c_int] * 6 + [C.c_void_p, C.c_size_t, C.c_void_p]
     lib.pvnet_motion_workspace_bytes.restype = C.c_size_t
     lib.pvnet_motion_workspace_bytes.argtypes = [C.c_int] * 4
@@ -88,7 +92,7 @@ def load_library() -> C.CDLL:
     lib.pvnet_vote_distribution.argtypes = [f32p, f32p] + ws_tail
     lib.pvnet_vote_tuning_reload.restype = None
     lib.pvnet_vote_tuning_reload.argtypes = []
-    if lib.pvnet_vote_abi_version() != 3:
+    if lib.pvnet_vote_abi_version() != 4:
         raise RuntimeError("pvnet_amd: libpvnet_vote.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib
@@ -526,10 +530,40 @@ def voting_for_hypothesis(direct, coords, hypo_pts, inliers, inlier_thresh):
     return None
 
 
-def generate_hypothesis_vanishing_point(*_a, **_k):
-    raise NotImplementedError("vanishing-point ops are out of scope (their only caller in the reference, "
-                              "ransac_voting_gpu.py:408-501, references undefined names) -- SURVEY.md section 2")
+def generate_hypothesis_vanishing_point(direct, coords, idxs):
+    """direct [tn,vn,2] f32, coords [tn,2] f32, idxs [hn,vn,2] i32 -> new [hn,vn,3] f32: homogeneous intersections
+    (x, y, z) of the two pixels' rays; z = 0 for parallel rays, (0, 0, 0) where the rays do not meet
+    (ransac_voting.cpp:57-75 -> ransac_voting_kernel.cu:170-266)."""
+    _check_input(direct, "direct", torch.float32)
+    _check_input(coords, "coords", torch.float32)
+    _check_input(idxs, "idxs", torch.int32)
+    tn, vn, _ = direct.shape
+    hn = idxs.shape[0]
+    if coords.shape != (tn, 2) or idxs.shape != (hn, vn, 2) or direct.shape[2] != 2:
+        raise RuntimeError("generate_hypothesis_vanishing_point: shape mismatch")
+    out = torch.empty((hn, vn, 3), dtype=torch.float32, device=direct.device)
+    with torch.cuda.device(direct.device):
+        _check(load_library().pvnet_generate_hypothesis_vanishing_point(
+            C.c_void_p(direct.data_ptr()), C.c_void_p(coords.data_ptr()), C.c_void_p(idxs.data_ptr()),
+            C.c_void_p(out.data_ptr()), tn, vn, hn, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            "pvnet_generate_hypothesis_vanishing_point")
+    return out
 
 
-def voting_for_hypothesis_vanishing_point(*_a, **_k):
-    raise NotImplementedError("vanishing-point ops are out of scope -- SURVEY.md section 2")
+def voting_for_hypothesis_vanishing_point(direct, coords, hypo_pts, inliers, inlier_thresh):
+    """in place: inliers [hn,vn,tn] uint8 gets a 1 wherever the pixel votes for the homogeneous hypothesis
+    hypo_pts [hn,vn,3] (ransac_voting.cpp:84-99 -> ransac_voting_kernel.cu:268-351)."""
+    _check_input(direct, "direct", torch.float32)
+    _check_input(coords, "coords", torch.float32)
+    _check_input(hypo_pts, "hypo_pts", torch.float32)
+    _check_input(inliers, "inliers", torch.uint8)
+    tn, vn, _ = direct.shape
+    hn = hypo_pts.shape[0]
+    if coords.shape != (tn, 2) or hypo_pts.shape != (hn, vn, 3) or inliers.shape != (hn, vn, tn):
+        raise RuntimeError("voting_for_hypothesis_vanishing_point: shape mismatch")
+    with torch.cuda.device(direct.device):
+        _check(load_library().pvnet_voting_for_hypothesis_vanishing_point(
+            C.c_void_p(direct.data_ptr()), C.c_void_p(coords.data_ptr()), C.c_void_p(hypo_pts.data_ptr()),
+            C.c_void_p(inliers.data_ptr()), tn, vn, hn, C.c_float(inlier_thresh),
+            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "pvnet_voting_for_hypothesis_vanishing_point")
+    return None

@@ -23,11 +23,11 @@ def test_exports_every_declared_symbol(lib):
     names = set(re.findall(r"\b(pvnet_[a-z0-9_]+)\s*\(", hdr))
     assert {"pvnet_vote_v3", "pvnet_vote_v3_profiled", "pvnet_generate_hypothesis", "pvnet_voting_for_hypothesis",
             "pvnet_vote_workspace_bytes", "pvnet_vote_layout", "pvnet_vote_abi_version", "pvnet_vote_tuning_reload",
-            "pvnet_vote_v3_stage_repeat",
-            "pvnet_vote_build_info"} <= names
+            "pvnet_vote_v3_stage_repeat", "pvnet_generate_hypothesis_vanishing_point",
+            "pvnet_voting_for_hypothesis_vanishing_point", "pvnet_vote_build_info"} <= names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/pvnet_vote.h but not exported"
-    assert lib.pvnet_vote_abi_version() == 3
+    assert lib.pvnet_vote_abi_version() == 4
     assert b"gfx950" in lib.pvnet_vote_build_info()
 
 

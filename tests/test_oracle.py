@@ -98,6 +98,75 @@ def test_voting_threshold_edge_and_skips():
     assert cref.voting_counts(direct0, coords0, hyp, -2.0)[0, 0] == 0
 
 
+def _vp_case(seed, tn=300, vn=4, hn=200):
+    """random rays plus every special case of the two vanishing-point kernels"""
+    rng = np.random.default_rng(seed)
+    coords = rng.integers(0, 200, (tn, 2)).astype(np.float32)
+    ang = rng.uniform(0, 2 * np.pi, (tn, vn))
+    direct = (np.stack([np.cos(ang), np.sin(ang)], -1) * rng.uniform(0.5, 2.0, (tn, vn, 1))).astype(np.float32)
+    idxs = rng.integers(0, tn, (hn, vn, 2)).astype(np.int32)
+    direct[3] = direct[5]            # parallel rays at different pixels: z = 0 exactly
+    idxs[0, :] = [3, 5]
+    idxs[1, :] = [7, 7]              # the same pixel twice: the zero vector
+    direct[9] = 0.0                  # a zero direction: zero line coordinates
+    idxs[2, :] = [9, 11]
+    direct[13, :, 0] = 0.0           # axis-aligned rays: val_x == 0 exactly (neither < 0 nor a sign conflict)
+    idxs[3, :] = [13, 15]
+    return coords, direct, idxs
+
+
+def test_vanishing_point_hand_cases():
+    """ransac_voting_kernel.cu:170-229, :268-310 on rays whose intersection is known"""
+    s = np.float32(np.sqrt(0.5))
+    coords = np.array([[0, 0], [10, 0], [0, 4], [10, 10]], np.float32)
+    direct = np.array([[[s, s]], [[-s, s]], [[s, s]], [[s, s]]], np.float32)  # [tn=4, vn=1, 2]
+    idxs = np.array([[[0, 1]],    # rays from (0,0) along (1,1) and from (10,0) along (-1,1) meet at (5,5)
+                     [[0, 2]],    # parallel (same direction, different pixels): a point at infinity, z = 0
+                     [[0, 3]],    # (0,0) and (10,10), both along (1,1): one and the same line
+                     [[1, 1]]], np.int32)
+    for hyp in (O.generate_hypothesis_vanishing_point(direct, coords, idxs, np.float64),
+                O.generate_hypothesis_vanishing_point(direct, coords, idxs, np.float32),
+                cref.generate_hypothesis_vanishing_point(direct, coords, idxs)):
+        assert hyp.shape == (4, 1, 3)
+        x, y, z = hyp[0, 0]
+        assert z != 0 and abs(x / z - 5) < 1e-5 and abs(y / z - 5) < 1e-5
+        assert hyp[1, 0, 2] == 0 and np.abs(hyp[1, 0, :2]).max() > 0      # direction of the common vanishing point
+        np.testing.assert_array_equal(hyp[3, 0], [0, 0, 0])
+        # the pixels that produced hypothesis 0 vote for it; pixel 3 lies on the line through it (|cos| = 1) but looks
+        # away from it: the direction is wrong (:306)
+        inl = O.voting_for_hypothesis_vanishing_point(direct, coords, hyp[:1].astype(np.float64), 0.99)
+        np.testing.assert_array_equal(inl[0, 0], [1, 1, 0, 0])
+        buf = np.zeros((1, 1, 4), np.uint8)
+        buf[0, 0, 3] = 9                                                   # the op only ever sets ones
+        cref.voting_for_hypothesis_vanishing_point(direct, coords, hyp[:1].astype(np.float32), buf, 0.99)
+        np.testing.assert_array_equal(buf[0, 0], [1, 1, 0, 9])
+    # where the affine op (pinned by the reference's device code) has an answer, x/z, y/z is that answer
+    coords, direct, idxs = _vp_case(1)
+    vp = O.generate_hypothesis_vanishing_point(direct, coords, idxs, np.float64)
+    aff = O.generate_hypothesis(direct, coords, idxs, np.float64)
+    ok = (np.abs(vp[..., 2]) > 1e-3) & (np.abs(aff).sum(-1) > 0)
+    assert ok.mean() > 0.3
+    assert np.abs(vp[ok][:, :2] / vp[ok][:, 2:3] - aff[ok]).max() < 1e-6 * max(1.0, np.abs(aff[ok]).max())
+
+
+@pytest.mark.parametrize("seed", [2, 5])
+def test_vanishing_point_numpy_f32_equals_c_bit_exact(seed):
+    coords, direct, idxs = _vp_case(seed)
+    hyp_np = O.generate_hypothesis_vanishing_point(direct, coords, idxs, np.float32)
+    hyp_c = cref.generate_hypothesis_vanishing_point(direct, coords, idxs)
+    assert hyp_np.dtype == np.float32 and hyp_np.tobytes() == hyp_c.tobytes()          # signed zeros included
+    assert (hyp_c[0, :, 2] == 0).all() and not hyp_c[1].any() and not hyp_c[2].any()
+    assert 0.2 < (np.abs(hyp_c).sum(-1) == 0).mean() < 0.95                           # rays that do not meet: zeros
+    hyp_c[4, :, :] = [coords[6, 0] * 2, coords[6, 1] * 2, 2]                           # a hypothesis ON pixel 6: norm2 = 0
+    for thresh in (0.9, 0.999):
+        inl_np = O.voting_for_hypothesis_vanishing_point(direct, coords, hyp_c, thresh, np.float32)
+        inl_c = np.zeros_like(inl_np)
+        cref.voting_for_hypothesis_vanishing_point(direct, coords, hyp_c, inl_c, thresh)
+        np.testing.assert_array_equal(inl_np, inl_c)
+        assert inl_c[:, :, 9].sum() == 0 and inl_c[4, :, 6].sum() == 0 and inl_c[1].sum() == 0
+        assert 0 < inl_c.sum() < inl_c.size // 4
+
+
 # ---------------------------------------------------------------- two restatements, bit for bit
 @pytest.mark.parametrize("seed", [0, 7])
 def test_numpy_f32_equals_c_bit_exact(seed):

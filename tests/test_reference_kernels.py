@@ -1,5 +1,5 @@
 """GPU parity tests against the REFERENCE'S OWN device code: lib/ransac_voting_gpu_layer/src/ransac_voting_kernel.cu
-(generate_hypothesis_kernel :11-49, voting_for_hypothesis_kernel :88-126) compiled for gfx950 from the reference
+(generate_hypothesis_kernel :11-49, voting_for_hypothesis_kernel :88-126, the vanishing-point pair :170-229, :268-310) compiled for gfx950 from the reference
 tree by `make -C oracle ref` (oracle/_ref/, git-ignored, travels with the tree to the GPU box) and run on the
 MI355X next to our kernels on identical device buffers.
 
@@ -66,6 +66,58 @@ def test_reference_kernels_equal_c_restatement_and_our_ops():
     ours = torch.zeros_like(inl_ref)
     voting.voting_for_hypothesis(d2, c, h2, ours, 0.99)
     assert torch.equal(ours, inl_ref)
+
+
+def test_vanishing_point_ops_equal_reference_device_code():
+    """the other two ops of the reference's extension (ransac_voting.cpp:57-99; kernels :170-229, :268-310): our HIP
+    ops == the reference's own device code == the plain-C restatement, bit for bit (signed zeros included), on real
+    compacted pixels plus every special case: parallel rays (z = 0), the same pixel twice, a zero direction,
+    axis-aligned rays, rays that do not meet (zeros), a hypothesis on a pixel, pre-set bytes of the in/out tensor."""
+    _, _, coords, direct = compacted(first=640, h=140, w=180, radius=18)
+    tn = coords.shape[0]
+    hn = 160
+    idxs = np.random.default_rng(4).integers(0, tn, (hn, 9, 2), dtype=np.int32)
+    direct[3] = direct[5]
+    idxs[0, :] = [3, 5]
+    idxs[1, :] = [7, 7]
+    direct[9] = 0.0
+    idxs[2, :] = [9, 11]
+    direct[13, :, 0] = 0.0
+    idxs[3, :] = [13, 15]
+    d, c, i = (torch.from_numpy(x).to(dev()) for x in (direct, coords, idxs))
+    hyp_ref = refkernels.generate_hypothesis_vanishing_point(d, c, i)
+    hyp_c = cref.generate_hypothesis_vanishing_point(direct, coords, idxs)
+    assert hyp_ref.shape == (hn, 9, 3)
+    assert hyp_ref.cpu().numpy().tobytes() == hyp_c.tobytes(), "C restatement != reference device code"
+    ours = voting.generate_hypothesis_vanishing_point(d, c, i)
+    assert ours.cpu().numpy().tobytes() == hyp_c.tobytes()
+    assert (hyp_c[0, :, 2] == 0).all() and not hyp_c[1].any() and not hyp_c[2].any()
+    zero = (np.abs(hyp_c).sum(-1) == 0).mean()
+    assert 0.05 < zero < 0.95                                   # some rays meet, some do not
+    hyp2 = hyp_c.copy()
+    hyp2[4, :, :] = [coords[6, 0] * 2, coords[6, 1] * 2, 2]     # a hypothesis on pixel 6 (norm2 < 1e-6)
+    h2 = torch.from_numpy(hyp2).to(dev())
+    for thresh in (0.9, 0.99, 0.999):
+        inl_ref = refkernels.voting_for_hypothesis_vanishing_point(d, c, h2, thresh)
+        inl_c = np.zeros((hn, 9, tn), np.uint8)
+        cref.voting_for_hypothesis_vanishing_point(direct, coords, hyp2, inl_c, thresh)
+        np.testing.assert_array_equal(inl_ref.cpu().numpy(), inl_c)
+        mine = torch.zeros((hn, 9, tn), dtype=torch.uint8, device=dev())
+        mine[5, 2, 17] = 7                                       # in/out: foreign bytes survive, ones are only ever set
+        voting.voting_for_hypothesis_vanishing_point(d, c, h2, mine, thresh)
+        want = inl_ref.clone()
+        want[5, 2, 17] = 1 if int(inl_ref[5, 2, 17]) else 7
+        assert torch.equal(mine, want)
+        assert 0 < int(inl_ref.sum()) < hn * 9 * tn              # (a coherent field: most pixels vote for most hypotheses)
+        assert int(inl_ref[:, :, 9].sum()) == 0 and int(inl_ref[4, :, 6].sum()) == 0
+    # the reference's argument checks, mirrored (ransac_voting.cpp:66-68, :91-94: CHECK_INPUT)
+    with pytest.raises(RuntimeError):
+        voting.generate_hypothesis_vanishing_point(d.cpu(), c, i)
+    with pytest.raises(RuntimeError):
+        voting.voting_for_hypothesis_vanishing_point(d, c, h2[:, :, :2], mine, 0.99)
+    import lib.ransac_voting_gpu_layer.ransac_voting as ext      # the module name the reference's driver imports (:2)
+    assert ext.generate_hypothesis_vanishing_point is voting.generate_hypothesis_vanishing_point
+    assert ext.voting_for_hypothesis_vanishing_point is voting.voting_for_hypothesis_vanishing_point
 
 
 @pytest.mark.parametrize("hn,thresh", [(128, 0.99), (256, 0.999)])

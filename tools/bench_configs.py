@@ -71,6 +71,52 @@ def run_plan(name, b, radius, hn, thresh, max_num=30000, steps=300):
         e1.record()
         torch.cuda.synchronize()
         qlat.append(e0.elapsed_time(e1) * 1e3)
+    # the same six launches replayed as ONE hipGraph (seed frozen at capture): does a graph launch beat six launches?
+    try:
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            plan(m, v, seed=3)
+            side.synchronize()
+            with torch.cuda.graph(g, stream=side):
+                plan(m, v, seed=3)
+        torch.cuda.synchronize()
+        want = plan(m, v, seed=3).clone()
+        for _ in range(5):
+            g.replay()
+        torch.cuda.synchronize()
+        same = bool(torch.equal(plan.out, want))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        g_issue = (time.perf_counter() - t0) / steps
+        torch.cuda.synchronize()
+        g_dt = (time.perf_counter() - t0) / steps
+        glat, gq = [], []
+        for i in range(30):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            glat.append(e0.elapsed_time(e1) * 1e3)
+        for i in range(20):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            for _ in range(8):
+                big @ big
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            gq.append(e0.elapsed_time(e1) * 1e3)
+        print(f"{name:44s} b={b:3d} hn={hn:5d} hipGraph replay of the plan (same result: {same}): {g_dt * 1e6:8.1f} us/call back to back "
+              f"(host issue {g_issue * 1e6:6.1f} us), idle-stream latency {np.median(glat):6.1f} us (min {min(glat):.1f}), queued "
+              f"{np.median(gq):6.1f} us (min {min(gq):.1f})", flush=True)
+    except Exception as e:  # a development aid: report, do not stop the other lines
+        print(f"{name:44s} hipGraph replay failed: {type(e).__name__}: {e}", flush=True)
     print(f"{name:44s} b={b:3d} hn={hn:5d} VotePlan: {dt * 1e6:8.1f} us/call back to back (host issue {t_issue * 1e6:6.1f} us), "
           f"GPU latency of one call from an idle stream {np.median(lat):6.1f} us (min {min(lat):.1f}), queued behind GPU work "
           f"{np.median(qlat):6.1f} us (min {min(qlat):.1f})", flush=True)
