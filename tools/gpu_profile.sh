@@ -17,4 +17,6 @@ if [ "$2" != "quick" ]; then
 ( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 -d $OUT/pmc_lds -o pmc -- $B --steps 10 --warmup 2 --score-repeats 4 > $OUT/pmc_lds.json 2> $OUT/pmc_lds.err )
 fi
 python tools/rocpd_summary.py $OUT $OUT/summary > /dev/null
+# the raw rocpd databases are tens of MiB each (gpurun merges at most 64 MiB back): keep the summaries only
+find $OUT -name '*.db' -size +1M -delete
 ls -la $OUT
