@@ -23,6 +23,9 @@
 
 namespace {
 
+// one unused VGPR granule beyond what a kernel uses: see PVNET_SPARE_VGPRS in pvnet_vote.hip
+#define PVNET_SPARE_VGPRS_(r) asm volatile("" ::: "v" #r)
+#define PVNET_SPARE_VGPRS(r) PVNET_SPARE_VGPRS_(r)
 constexpr int NN_T = 256;  // queries per workgroup = reference points per LDS tile
 constexpr unsigned long long NN_NONE = ((unsigned long long)0x7F7FFFFFu << 32) | 0xFFFFFFFFull;  // (FLT_MAX, no index)
 
@@ -31,6 +34,7 @@ __global__ __launch_bounds__(NN_T) void nn_search_kernel(const float* __restrict
                                                          unsigned long long* __restrict__ best, int32_t* __restrict__ idxs,
                                                          int pn1, int pn2, int slice, int exclude_self) {
 #pragma clang fp contract(off)
+    PVNET_SPARE_VGPRS(63);
     __shared__ float4 s_ref[NN_T];
     const int bi = blockIdx.z;
     const int q = blockIdx.x * NN_T + threadIdx.x;
@@ -79,12 +83,14 @@ __global__ __launch_bounds__(NN_T) void nn_search_kernel(const float* __restrict
 }
 
 __global__ __launch_bounds__(256) void nn_init_kernel(unsigned long long* __restrict__ best, size_t n) {
+    PVNET_SPARE_VGPRS(23);
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) best[i] = NN_NONE;
 }
 
 __global__ __launch_bounds__(256) void nn_final_kernel(const unsigned long long* __restrict__ best,
                                                        int32_t* __restrict__ idxs, size_t n) {
+    PVNET_SPARE_VGPRS(23);
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
         const unsigned long long k = best[i];

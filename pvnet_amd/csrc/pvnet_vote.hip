@@ -68,6 +68,19 @@ constexpr int SEG_WORDS = 64;          // a segment = 64 words = 4096 pixels: th
 __device__ __forceinline__ void small_stage_prio() {
     if (PVNET_SMALL_PRIO) __builtin_amdgcn_s_setprio(PVNET_SMALL_PRIO);
 }
+// Every kernel asks for at least one granule (8) of VGPRs MORE than it uses: an empty asm statement that names a high
+// register as clobbered raises .amdhsa_next_free_vgpr without costing an instruction.  Reason (round 2, the compaction
+// flake; profiles/r02_compaction_flake_investigation.txt, tools/experiments/k2_flake/): compact_kernel<false,1>
+// returned up to 64 records of one wave from pixels a few ranks away in 40-100 % of the runs whenever (a) its code used
+// the wave's VGPR allocation up to the last granule and (b) two or more of its workgroups shared a CU.  The SAME
+// instruction stream, assembled with .amdhsa_next_free_vgpr raised from 24 to 32 (nothing else changed), never failed in
+// 300 runs; moving the four highest registers' roles to v8..v11 at the original allocation did not fail either; with
+// one workgroup per CU (100 KB of dynamic LDS) it did not fail.  What exactly goes wrong in the top granule was not found
+// (ruled out: wait counts, the barrier, LDS visibility, store-data / LDS-address / 64-bit-shift hazards, loads in flight
+// at s_endpgm; a stand-alone register-persistence stress test does not reproduce it), so the rule is empirical -- and
+// tools/check_kernel_resources.py enforces it for every kernel of the library at build time.
+#define PVNET_SPARE_VGPRS_(r) asm volatile("" ::: "v" #r)
+#define PVNET_SPARE_VGPRS(r) PVNET_SPARE_VGPRS_(r)
 constexpr int K1_WAVES = PVNET_K1_WAVES;  // waves per K1 workgroup (one workgroup = one segment): measured 4 -> 22.5 us,
                                         // 8 -> 20.6 us, 16 -> 19.4 us for the 78.6 MB int64 masks of a batch of 32
 constexpr int K1B_WAVES = 4;            // K1b (usually a no-op): small workgroups,
@@ -282,6 +295,7 @@ __device__ __forceinline__ bool load_fg(const void* m, int64_t off) {
 
 template <int DT>
 __global__ __launch_bounds__(64 * K1_WAVES) void mask_bits_kernel(VoteParams P) {
+    PVNET_SPARE_VGPRS(31);
     small_stage_prio();
     const int bi = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -335,6 +349,7 @@ __global__ __launch_bounds__(64 * K1_WAVES) void mask_bits_kernel(VoteParams P) 
 // K1b: Bernoulli subsample when tn0 > max_num                 (ransac_voting_gpu.py:537-540)
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * K1B_WAVES) void subsample_kernel(VoteParams P) {
+    PVNET_SPARE_VGPRS(31);
     small_stage_prio();
     const int bi = blockIdx.y;
     // tn0 = sum of this image's segment counts as K1 wrote them (seg0: blocks of this launch rewrite only seg).
@@ -380,20 +395,17 @@ __global__ __launch_bounds__(64 * K1B_WAVES) void subsample_kernel(VoteParams P)
 // ------------------------------------------------------------------------------------------------------------
 template <bool LITERAL, int K2_KG, int VT>  // K2_KG key-points per block: grid.z = ceil(vn / K2_KG); VT: field element type
 __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
+    if (K2_KG == 1) PVNET_SPARE_VGPRS(55); else if (K2_KG <= 3) PVNET_SPARE_VGPRS(71); else PVNET_SPARE_VGPRS(103);
     small_stage_prio();
     const int bi = blockIdx.y;
     const int w0 = blockIdx.x * K2_WORDS_PER_BLOCK;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint64_t* bw = P.bits + (size_t)bi * P.words;
 
-    // volatile: with plain LDS arrays one build of the <false, 1> instantiation (hipcc 7.2, gfx950) returned, in ~40 % of
-    // the runs, one wave's 64 records from pixels two ranks further on -- the word offsets of a neighbouring segment, i.e.
-    // LDS contents from before this workgroup's barrier; the same source compiled a commit earlier never did (0 / 400).
-    // Forcing every access to be performed as written removes it (0 / 600, tools/rep_flake3.py) at no measurable cost.
-    __shared__ volatile int s_red[4];
-    __shared__ volatile int s_woff[K2_WORDS_PER_BLOCK];
-    __shared__ volatile uint64_t s_word[K2_WORDS_PER_BLOCK];
-    __shared__ volatile int s_total;
+    __shared__ int s_red[4];
+    __shared__ int s_woff[K2_WORDS_PER_BLOCK];
+    __shared__ uint64_t s_word[K2_WORDS_PER_BLOCK];
+    __shared__ int s_total;
 
     // pixels kept before this block = sum of the earlier segments' counts (<= a few hundred ints)
     const int32_t* sg = P.seg + bi * P.nseg;
@@ -427,16 +439,18 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
     const int k0 = blockIdx.z * K2_KG;
     const int T = s_total;
     auto locate = [&](int t, int& pos, int& p) {
+        // branch-free: every decision is the sign bit of a difference turned into an all-ones / zero mask
         int lo = 0;
 #pragma unroll
-        for (int st = 32; st > 0; st >>= 1)
-            if (lo + st < K2_WORDS_PER_BLOCK && s_woff[lo + st] <= t) lo += st;
-        unsigned long long wd = s_word[lo];
+        for (int st = 32; st > 0; st >>= 1) lo += st & ~((t - s_woff[lo + st]) >> 31);  // s_woff[lo + st] <= t; lo + st <= 63
+        const unsigned long long wd = s_word[lo];
         int r = t - s_woff[lo], bitpos = 0;
 #pragma unroll
         for (int st = 32; st > 0; st >>= 1) {
             const int c = __popcll((wd >> bitpos) & ((1ull << st) - 1ull));
-            if (r >= c) { bitpos += st; r -= c; }
+            const int take = ~((r - c) >> 31);  // r >= c
+            bitpos += st & take;
+            r -= c & take;
         }
         pos = base + t;
         p = (w0 + lo) * 64 + bitpos;
@@ -551,6 +565,7 @@ __device__ __forceinline__ void plan_image(const VoteParams& P, int bi) {
 // ------------------------------------------------------------------------------------------------------------
 template <bool LITERAL>
 __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
+    PVNET_SPARE_VGPRS(47);
     small_stage_prio();
     // Workgroups go to the 8 XCDs round-robin by linear id; every block of image bi is placed on XCD bi % 8 so that
     // the two random 16-byte record reads per hypothesis (several per 128-byte line of the image's records) hit
@@ -644,6 +659,7 @@ constexpr int NB = 4;  // pixels per inner-loop step (4 ds_read_b128 + 4 ds_read
 
 template <int HPL, bool LITERAL>
 __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
+    if (HPL == 8) PVNET_SPARE_VGPRS(95); else PVNET_SPARE_VGPRS(71);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int G = P.wg_g, S = P.wg_s;  // G * S == 4 waves
     const int npx = S * P.chunk;
@@ -780,6 +796,7 @@ __device__ __forceinline__ int votes_of(unsigned acc) { return (int)(((acc >> 23
 // measured live and free of launch gaps.
 template <int MH, bool TIMED>
 __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
+    if (MH == 8) PVNET_SPARE_VGPRS(159); else if (MH == 4) PVNET_SPARE_VGPRS(143); else PVNET_SPARE_VGPRS(111);
     unsigned long long* __restrict__ stamps = reinterpret_cast<unsigned long long*>(P.pix);
     if (TIMED && threadIdx.x == 0) stamps[2 * blockIdx.x] = (unsigned long long)wall_clock64();
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -877,6 +894,7 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
 // profiling helper of pvnet_vote_v3_stage_repeat: acc[0] += (max end - min start) over the n workgroup slots
 __global__ __launch_bounds__(256) void ts_collect_kernel(const unsigned long long* __restrict__ stamps, int n,
                                                          unsigned long long* __restrict__ acc, int clear) {
+    PVNET_SPARE_VGPRS(39);
     unsigned long long lo = ~0ull, hi = 0ull;
     for (int i = threadIdx.x; i < n; i += 256) {
         const unsigned long long a = stamps[2 * i], b = stamps[2 * i + 1];
@@ -904,6 +922,7 @@ constexpr int RT = PVNET_RT;  // threads per (image, key-point) (measured: 256 -
 constexpr int RW = RT / 64;
 template <bool LITERAL>
 __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
+    PVNET_SPARE_VGPRS(111);
     small_stage_prio();
     const int k = blockIdx.x, bi = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1057,6 +1076,7 @@ __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
 // vote (literal float32 test, threshold `thresh`, 0.999 in the reference) for the given points.
 __global__ __launch_bounds__(256) void confidence_kernel(VoteParams P, const float* __restrict__ pts, float thresh,
                                                          float* __restrict__ conf) {
+    PVNET_SPARE_VGPRS(47);
     const int k = blockIdx.x, bi = blockIdx.y;
     const size_t bk = (size_t)bi * P.vn + k;
     const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
@@ -1080,6 +1100,7 @@ __global__ __launch_bounds__(256) void confidence_kernel(VoteParams P, const flo
 // of the hypotheses about `mean`, weights = inlier ratio where it is within 0.1 of the key-point's best, else 0.
 __global__ __launch_bounds__(256) void distribution_kernel(VoteParams P, const float* __restrict__ mean,
                                                            float* __restrict__ cov) {
+    PVNET_SPARE_VGPRS(47);
     const int k = blockIdx.x, bi = blockIdx.y;
     const size_t bk = (size_t)bi * P.vn + k;
     const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
@@ -1128,6 +1149,7 @@ __global__ __launch_bounds__(256) void distribution_kernel(VoteParams P, const f
 // of the planar field), one block per (image, key-point) adds the segment sums in order and divides.
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void motion_partial_kernel(VoteParams P, double* __restrict__ part) {
+    PVNET_SPARE_VGPRS(55);
     const int sgi = blockIdx.x, bi = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (P.seg0[bi * P.nseg + sgi] == 0) return;  // block-uniform; the final kernel skips this segment's slots too
@@ -1164,6 +1186,7 @@ __global__ __launch_bounds__(256) void motion_partial_kernel(VoteParams P, doubl
 
 __global__ __launch_bounds__(64) void motion_final_kernel(VoteParams P, const double* __restrict__ part,
                                                           float* __restrict__ out) {
+    PVNET_SPARE_VGPRS(31);
     const int k = blockIdx.x, bi = blockIdx.y, lane = threadIdx.x;
     double sx = 0.0, sy = 0.0;
     int n = 0;
@@ -1191,6 +1214,7 @@ __global__ __launch_bounds__(256) void op_generate_hypothesis_kernel(const float
                                                                      const float* __restrict__ coords,
                                                                      const int32_t* __restrict__ idxs,
                                                                      float* __restrict__ hyp, int tn, int vn, int hn) {
+    PVNET_SPARE_VGPRS(31);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= hn * vn) return;
     const int k = i % vn;
@@ -1211,6 +1235,7 @@ __global__ __launch_bounds__(256) void op_voting_kernel(const float* __restrict_
                                                         const float* __restrict__ coords,
                                                         const float* __restrict__ hyp, uint8_t* __restrict__ inliers,
                                                         int tn, int vn, int hn, float thresh, int hslice) {
+    PVNET_SPARE_VGPRS(31);
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int k = blockIdx.y;
     const int h0 = blockIdx.z * hslice;
@@ -1235,6 +1260,7 @@ __global__ __launch_bounds__(256) void op_generate_hypothesis_vp_kernel(const fl
                                                                         const int32_t* __restrict__ idxs,
                                                                         float* __restrict__ hyp, int tn, int vn, int hn) {
 #pragma clang fp contract(off)
+    PVNET_SPARE_VGPRS(31);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= hn * vn) return;
     const int k = i % vn;
@@ -1268,6 +1294,7 @@ __global__ __launch_bounds__(256) void op_voting_vp_kernel(const float* __restri
                                                            const float* __restrict__ hyp, uint8_t* __restrict__ inliers,
                                                            int tn, int vn, int hn, float thresh, int hslice) {
 #pragma clang fp contract(off)
+    PVNET_SPARE_VGPRS(31);
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int k = blockIdx.y;
     const int h0 = blockIdx.z * hslice;

@@ -135,6 +135,24 @@ def test_oversized_matrix_pipe_items_are_refused(monkeypatch):
     voting.vote_layout(2, 120, 160, 9, 100, 30000)  # and an environment change alone does nothing until reloaded
 
 
+def test_every_kernel_keeps_a_spare_vgpr_granule(tmp_path):
+    """round 2's compaction flake: identical code failed in 98 % of the runs when it used its VGPR allocation to the top
+    and never with one granule more (profiles/r02_compaction_flake_investigation.txt).  Every kernel of both sources must
+    allocate at least 8 VGPRs beyond the highest one an instruction names (PVNET_SPARE_VGPRS); the checker is checked on
+    a hand-made violation."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_kernel_resources", os.path.join(ROOT, "tools", "check_kernel_resources.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    assert chk.main([]) == 0
+    body = ("kern:\n\tv_add_u32_e32 v23, v0, v1\n\ts_endpgm\n.Lfunc_end0:\n"
+            "\t.amdhsa_kernel kern\n\t\t.amdhsa_next_free_vgpr %d\n\t.end_amdhsa_kernel\n")
+    tight, roomy = tmp_path / "tight.s", tmp_path / "roomy.s"
+    tight.write_text(body % 24)
+    roomy.write_text(body % 32)
+    assert chk.main([str(tight)]) == 1 and chk.main([str(roomy)]) == 0
+
+
 def test_vote_epilogue_keeps_mfma_hazard_distance(tmp_path):
     """vote8 reads MFMA results from inline asm, where LLVM inserts no XDL-write -> VALU-read wait states: the generated
     assembly of every matrix-pipe scoring kernel is re-checked (tools/check_mfma_hazard.py), and the checker itself is
