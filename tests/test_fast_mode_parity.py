@@ -306,9 +306,11 @@ def test_half_precision_fields_and_logits_are_read_in_place(dt):
 
 @pytest.mark.parametrize("kg", ["1", "3", "9"])
 def test_compaction_is_deterministic_for_every_tiling(kg, monkeypatch):
-    """regression: one build of compact_kernel<false, 1> returned, in ~40 % of the runs, one wave's 64 records from pixels
-    two ranks further on (LDS word offsets read as a neighbouring segment left them); the LDS arrays of K2 are volatile
-    since.  80 repeated calls per tiling must reproduce the records, hypotheses and counts of the first bit for bit."""
+    """regression: one build of compact_kernel<false, 1> returned, in 40-100 % of the calls, up to 64 records of one wave
+    from pixels a few ranks away -- tied to "VGPR allocation used to its last granule + a second workgroup on the CU"
+    (profiles/r02_compaction_flake_investigation.txt); every kernel keeps a spare granule since and the rank search is
+    branch-free.  80 repeated calls per tiling must reproduce the records, hypotheses and counts of the first bit for bit
+    (3 images x 9 key-points at tiling 1 = 378 workgroups: more than one per CU, the condition that failed)."""
     mask, planar, _ = synth.make_batch(3, first_index=1300, h=200, w=280, radius=31, noise=True, background="normal")
     m, v = to_dev(mask, planar)
     monkeypatch.setenv("PVNET_COMPACT_KG", "3")
