@@ -66,7 +66,7 @@ PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32
 MFMA_FLOP_PER_PAIR = 2 * (2 * 32 * 32 * 16) / (32 * 32)  # two 32x32x16 MFMAs (cr, dt) per 32x32 pair tests = 64
 N_SIMD = 256 * 4
 N_XCD = 8
-PATH_KERNELS = ("mask_bits_kernel", "subsample_kernel", "compact_kernel", "hypothesis_kernel", "score_mfma_kernel",
+PATH_KERNELS = ("mask_bits_kernel", "compact_kernel", "hypothesis_kernel", "score_mfma_kernel",
                 "select_refine_kernel")
 
 

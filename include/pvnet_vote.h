@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PVNET_VOTE_ABI_VERSION 4
+#define PVNET_VOTE_ABI_VERSION 5
 
 /* negative library error codes */
 #define PVNET_E_BADARG      (-1)   /* null pointer / non-positive size / unsupported dtype or stride */
@@ -77,7 +77,7 @@ typedef struct PvnetVoteLayout {
     int32_t hgroups;        /* hypothesis groups per key-point = ceil(hn / (64*hpl)) rounded up to wg_g     */
     int32_t hn_pad;         /* hgroups * 64 * hpl                                                           */
     size_t off_ctrl;        /* int32 [b][8]: tn0, tn, status, item_base, nchunks, -, -, -  ; then [8] global */
-    size_t off_bits;        /* uint64 [b][words]           foreground (after subsampling) bit mask          */
+    size_t off_bits;        /* uint64 [b][words]           foreground bit mask (as the mask has it: before thinning) */
     size_t off_pix;         /* int32  [b][cap]             linear pixel index y*w+x of compacted pixel t    */
     size_t off_rec;         /* float4 [b][vn][cap]         record (x, y, ux, uy): pixel and its RAW direction for the
                                                            key-point (fast mode: zero when |u| < 1e-6, which never votes,
@@ -87,7 +87,8 @@ typedef struct PvnetVoteLayout {
                                scoring kernel adds its counts into `counts` with integer atomics (PVNET_SCORE_ATOMIC=1) */
     size_t off_counts;      /* int32  [b][vn][hn_pad]      inlier count of every hypothesis                 */
     size_t off_win;         /* int32  [b][vn][2]           (winner index, winner count)                     */
-    size_t off_seg;         /* int32  [2][b][nseg]         foreground count of every 4096-pixel segment     */
+    size_t off_seg;         /* int32  [2][b][nseg]         ([1] = foreground count of every 4096-pixel segment), then,
+                             *                              if max_num < h*w, uint16 [b][nseg][1024] cumulative histograms   */
     size_t off_items;       /* int32x4 [max items]         scoring work items (image, kp, chunk group, slice) */
     size_t off_hypb;        /* uint4  [b][vn][hn_pad][2]   fast mode: hypotheses as bf16x3 MFMA B operands         */
     size_t total_bytes;
@@ -107,7 +108,9 @@ size_t pvnet_vote_workspace_bytes(int b, int h, int w, int vn, int hn, int max_n
  *   vertex          [b,h,w,vn,2] float32, element strides vertex_strides[5] (any; planar in practice)
  *   hn              round_hyp_num
  *   inlier_thresh, min_num, max_num   as the reference's keyword arguments
- *   seed            counter-RNG seed (pixel pairs when idxs == NULL; Bernoulli subsample when tn0 > max_num)
+ *   seed            counter-RNG seed (pixel pairs when idxs == NULL; Bernoulli subsample when tn0 > max_num:
+ *                   a pixel is kept with probability ceil(1024 max_num / tn0) / 1024 -- the reference's max_num / tn0
+ *                   rounded up to a multiple of 1/1024)
  *   image_base      global index of image 0 of this call: the RNG stream of image i is image_base + i, so a batch
  *                   sharded over GPUs draws exactly what the unsharded batch would (0 for a whole batch)
  *   idxs            NULL, or int32 [b,hn,vn,2] pixel-pair indices into each image's compacted list
@@ -137,9 +140,9 @@ int pvnet_vote_v3_logits(const float* seg_pred, const int64_t seg_strides[4], in
 
 /* Same call, timed stage by stage with hipEvents on `stream`; synchronises the stream before returning.
  * stage_ms (host, PVNET_NUM_STAGES floats) receives the GPU time of each stage of this call. bench/profiling only. */
-#define PVNET_STAGE_MASK      0   /* mask -> bit mask + foreground count          (HBM read of the mask)     */
-#define PVNET_STAGE_SUBSAMPLE 1   /* Bernoulli subsample when tn0 > max_num                                  */
-#define PVNET_STAGE_COMPACT   2   /* order-preserving compaction + vector gather  (HBM read of fg vectors)   */
+#define PVNET_STAGE_MASK      0   /* mask -> bit mask + segment counts + thinning histograms (HBM read of the mask) */
+#define PVNET_STAGE_SUBSAMPLE 1   /* EMPTY since ABI 5 (was the Bernoulli-subsample launch): always ~0               */
+#define PVNET_STAGE_COMPACT   2   /* thinning when tn0 > max_num + order-preserving compaction + vector gather       */
 #define PVNET_STAGE_HYP       3   /* hypothesis generation + per-image work-item plan                        */
 #define PVNET_STAGE_SCORE     4   /* inlier scoring (dominant; matrix pipe + VALU compare)                   */
 #define PVNET_STAGE_REFINE    5   /* arg-max + least-squares refinement                                      */

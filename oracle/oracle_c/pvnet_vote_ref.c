@@ -205,11 +205,8 @@ int ref_vote_v3_base(const uint8_t* fg, const float* vertex, const int64_t* vs, 
         for (int p = 0; p < h * w; ++p) tn0 += m[p] != 0;                          /* :527-528 */
         if (tn0 < min_num) continue;                                                /* :531-534 */
         uint64_t thr = 1ull << 32;
-        if (tn0 > max_num) {                                                        /* :537-540 */
-            float p = (float)max_num / (float)tn0;
-            double t = ceil((double)p * 4294967296.0);
-            thr = t >= 4294967296.0 ? (1ull << 32) : (uint64_t)t;
-        }
+        if (tn0 > max_num)                                                          /* :537-540, probability rounded */
+            thr = (uint64_t)((1024ll * max_num + tn0 - 1) / tn0) << 22;             /* up to k / 1024 (oracle .py) */
         float* coords = (float*)scratch(&tl_buf[0], &tl_cap[0], sizeof(float) * 2 * (size_t)tn0);
         float* direct = (float*)scratch(&tl_buf[1], &tl_cap[1], sizeof(float) * 2 * (size_t)vn * tn0);
         int tn = 0;

@@ -87,9 +87,16 @@ def draw_idxs(seed: int, image: int, hn: int, vn: int, tn: int) -> np.ndarray:
 
 
 def subsample_threshold(max_num: int, tn0: int) -> int:
-    """keep  <=>  rng_u32 < threshold ; p = max_num / float32(tn0) as ransac_voting_gpu.py:539."""
-    p = np.float32(max_num) / np.float32(tn0)
-    return int(min(np.ceil(np.float64(p) * 4294967296.0), 4294967296.0))
+    """keep  <=>  rng_u32 < threshold.  ransac_voting_gpu.py:537-540 keeps a pixel with probability max_num / tn0 when
+    tn0 > max_num; here the probability is rounded UP to the next multiple of 1/1024 -- k = ceil(1024 max_num / tn0),
+    threshold = k << 22, i.e. keep <=> (rng >> 22) < k -- so that the mask kernel can count, per 4096-pixel segment, how
+    many pixels every one of the 1024 possible decisions keeps (a cumulative histogram of the top ten bits) before tn0 is
+    known, and compaction needs no separate thinning launch.  Expected kept pixels: tn0 k / 256 in [max_num,
+    max_num + tn0 / 1024)."""
+    if tn0 <= max_num:
+        return 1 << 32
+    k = (1024 * int(max_num) + int(tn0) - 1) // int(tn0)
+    return k << 22
 
 
 def subsample_keep(seed: int, image: int, npix: int, max_num: int, tn0: int) -> np.ndarray:

@@ -10,9 +10,9 @@
 //
 // Stages (one launch each, all images of the batch at once):
 //   K1 mask_bits      mask (any int dtype / f32, any strides) -> 1 bit per pixel + per-segment counts  [HBM read]
-//   K1b subsample     Bernoulli(max_num/tn0) thinning of the bit mask when tn0 > max_num (device decision; a
-//                     few scalar loads and exit otherwise)
-//   K2 compact        order-preserving (raster) compaction: segment counts + wave scan of word popcounts give
+//                     + per segment the cumulative histogram of the thinning decisions (Bernoulli(k / 256) with
+//                     k = ceil(256 max_num / tn0), decided on the device once tn0 is known)
+//   K2 compact        thins its own segment when tn0 > max_num, then order-preserving (raster) compaction: segment counts + wave scan of word popcounts give
 //                     every kept pixel its slot; one thread per kept pixel gathers its vn direction vectors
 //                     straight from the strided field (planar in practice -> consecutive lanes read
 //                     consecutive addresses) and writes ONE float4 record per (pixel, key-point):
@@ -54,7 +54,7 @@ __device__ constexpr float kF1e6 = 0x1.0c6f7ap-20f;
 constexpr int CTRL_STRIDE = 8;
 enum { C_TN0 = 0, C_TN = 1, C_STATUS = 2, C_ITEM_BASE = 3, C_NCHUNKS = 4, C_OX = 5, C_OY = 6 };
 
-constexpr int SEG_WORDS = 64;          // a segment = 64 words = 4096 pixels: the unit of K1 / K1b / K2 workgroups
+constexpr int SEG_WORDS = 64;          // a segment = 64 words = 4096 pixels: the unit of K1 / K2 workgroups
 #ifndef PVNET_K1_WAVES
 #define PVNET_K1_WAVES 16
 #endif
@@ -83,12 +83,10 @@ __device__ __forceinline__ void small_stage_prio() {
 #define PVNET_SPARE_VGPRS(r) PVNET_SPARE_VGPRS_(r)
 constexpr int K1_WAVES = PVNET_K1_WAVES;  // waves per K1 workgroup (one workgroup = one segment): measured 4 -> 22.5 us,
                                         // 8 -> 20.6 us, 16 -> 19.4 us for the 78.6 MB int64 masks of a batch of 32
-constexpr int K1B_WAVES = 4;            // K1b (usually a no-op): small workgroups,
-constexpr int K1B_BLOCKS = 8;           // ... at least this many per image (more for small batches), each walking
-                                        // its share of the segments when thinning is needed
-constexpr int K1B_WORDS_PER_WAVE = SEG_WORDS / K1B_WAVES;
 constexpr int K1_WORDS_PER_WAVE = SEG_WORDS / K1_WAVES;  // independent loads in flight per lane
 constexpr int K2_WORDS_PER_BLOCK = SEG_WORDS;
+constexpr int THIN_BITS = 10;          // thinning probability = k / 2^THIN_BITS (oracle: subsample_threshold)
+constexpr int THIN_BINS = 1 << THIN_BITS;
 constexpr int PAD = 8;                 // scoring consumes records 8 at a time; tails are padded with sentinels
 
 struct VoteParams {
@@ -109,6 +107,7 @@ struct VoteParams {
     int4* items;
     int32_t* seg;
     int32_t* seg0;
+    uint16_t* cum;    // [b][nseg][THIN_BINS] cumulative histograms of the thinning decisions; NULL when max_num >= h*w
     int nseg;
     uint64_t* bits;
     int32_t* pix;
@@ -295,7 +294,7 @@ __device__ __forceinline__ bool load_fg(const void* m, int64_t off) {
 
 template <int DT>
 __global__ __launch_bounds__(64 * K1_WAVES) void mask_bits_kernel(VoteParams P) {
-    PVNET_SPARE_VGPRS(31);
+    PVNET_SPARE_VGPRS(39);
     small_stage_prio();
     const int bi = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -337,56 +336,44 @@ __global__ __launch_bounds__(64 * K1_WAVES) void mask_bits_kernel(VoteParams P) 
     __shared__ int s_cnt[K1_WAVES];
     if (lane == 0) s_cnt[wave] = cnt;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int t = 0;
-        for (int i = 0; i < K1_WAVES; ++i) t += s_cnt[i];
-        P.seg[bi * P.nseg + blockIdx.x] = t;   // foreground pixels of this 4096-pixel segment (thinned by K1b)
-        P.seg0[bi * P.nseg + blockIdx.x] = t;  // ... as the mask has them (tn0 = their sum)
-    }
-}
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < K1_WAVES; ++i) t += s_cnt[i];
+    if (threadIdx.x == 0) P.seg0[bi * P.nseg + blockIdx.x] = t;  // foreground pixels of this 4096-pixel segment (tn0 = their sum)
 
-// ------------------------------------------------------------------------------------------------------------
-// K1b: Bernoulli subsample when tn0 > max_num                 (ransac_voting_gpu.py:537-540)
-// ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * K1B_WAVES) void subsample_kernel(VoteParams P) {
-    PVNET_SPARE_VGPRS(31);
-    small_stage_prio();
-    const int bi = blockIdx.y;
-    // tn0 = sum of this image's segment counts as K1 wrote them (seg0: blocks of this launch rewrite only seg).
-    // Every wave reduces it for itself: no barrier, no atomics.  K1B_BLOCKS blocks per image: in the common case
-    // (nothing to thin) the launch is a few hundred blocks that load ~75 ints and exit.
-    int tn0 = 0;
-    for (int j = threadIdx.x & 63; j < P.nseg; j += 64) tn0 += P.seg0[bi * P.nseg + j];
-    tn0 = __builtin_amdgcn_readfirstlane(wave_reduce_add(tn0));
-    if (tn0 <= P.max_num) return;  // wave-uniform
-    const float p = (float)P.max_num / (float)tn0;
-    const double t = ceil((double)p * 4294967296.0);
-    if (t >= 4294967296.0) return;
-    const uint32_t thr = (uint32_t)t;
+    // Thinning (ransac_voting_gpu.py:537-540) keeps a pixel when the top THIN_BITS bits of its random word are below
+    // k = ceil(2^THIN_BITS max_num / tn0) -- but tn0 is only known when every segment has been counted.  So a segment
+    // WITH foreground (one in ten) also counts how many of its pixels EVERY possible k would keep (a cumulative histogram
+    // of those bits, 2 KB), and the compaction kernel, which sums the segment counts anyway, picks its column: no separate
+    // thinning launch.  Only when thinning can happen at all (max_num < h*w: P.cum is set).
+    if (P.cum == nullptr || t == 0) return;  // block-uniform
+    __shared__ int s_hist[THIN_BINS];
+    for (int i = threadIdx.x; i < THIN_BINS; i += 64 * K1_WAVES) s_hist[i] = 0;
+    __syncthreads();
     const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_SUB, (uint32_t)(P.image_base + bi));
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __shared__ int s_cnt[K1B_WAVES];
-    for (int sgi = blockIdx.x; sgi < P.nseg; sgi += gridDim.x) {  // this block's segments
-        const int word0 = (sgi * K1B_WAVES + wave) * K1B_WORDS_PER_WAVE;
-        int cnt = 0;
-        for (int i = 0; i < K1B_WORDS_PER_WAVE; ++i) {
-            const int j = word0 + i;
-            if (j >= P.words) break;
-            const unsigned long long word = P.bits[(size_t)bi * P.words + j];
-            if (word == 0) continue;
-            const bool keep = ((word >> lane) & 1ull) && pvnet_rng_at(key, (uint32_t)(j * 64 + lane)) < thr;
-            const unsigned long long m = __ballot(keep);
-            if (lane == 0) P.bits[(size_t)bi * P.words + j] = m;
-            cnt += __popcll(m);
+#pragma unroll
+    for (int i = 0; i < K1_WORDS_PER_WAVE; ++i)
+        if (f[i]) atomicAdd(&s_hist[pvnet_rng_at(key, (uint32_t)((word0 + i) * 64 + lane)) >> (32 - THIN_BITS)], 1);
+    __syncthreads();
+    if (wave == 0) {  // inclusive prefix over the bins: cum[k - 1] = pixels of this segment kept at threshold k
+        constexpr int PER = THIN_BINS / 64;  // consecutive bins per lane
+        int h[PER], mine = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            mine += s_hist[PER * lane + i];
+            h[i] = mine;
         }
-        if (lane == 0) s_cnt[wave] = cnt;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int tt = 0;
-            for (int i = 0; i < K1B_WAVES; ++i) tt += s_cnt[i];
-            P.seg[bi * P.nseg + sgi] = tt;
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += u;
         }
-        __syncthreads();
+        const int e = incl - mine;
+        uint16_t* dst = P.cum + ((size_t)bi * P.nseg + blockIdx.x) * THIN_BINS + PER * lane;
+#pragma unroll
+        for (int i = 0; i < PER; i += 2)
+            *reinterpret_cast<uint32_t*>(dst + i) = (uint32_t)(e + h[i]) | ((uint32_t)(e + h[i + 1]) << 16);
     }
 }
 
@@ -395,7 +382,7 @@ __global__ __launch_bounds__(64 * K1B_WAVES) void subsample_kernel(VoteParams P)
 // ------------------------------------------------------------------------------------------------------------
 template <bool LITERAL, int K2_KG, int VT>  // K2_KG key-points per block: grid.z = ceil(vn / K2_KG); VT: field element type
 __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
-    if (K2_KG == 1) PVNET_SPARE_VGPRS(55); else if (K2_KG <= 3) PVNET_SPARE_VGPRS(71); else PVNET_SPARE_VGPRS(103);
+    if (K2_KG == 1) PVNET_SPARE_VGPRS(39); else if (K2_KG <= 3) PVNET_SPARE_VGPRS(55); else PVNET_SPARE_VGPRS(87);
     small_stage_prio();
     const int bi = blockIdx.y;
     const int w0 = blockIdx.x * K2_WORDS_PER_BLOCK;
@@ -403,20 +390,30 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
     const uint64_t* bw = P.bits + (size_t)bi * P.words;
 
     __shared__ int s_red[4];
+    __shared__ int s_tot[4];
     __shared__ int s_woff[K2_WORDS_PER_BLOCK];
     __shared__ uint64_t s_word[K2_WORDS_PER_BLOCK];
+    __shared__ uint16_t s_piece[4 * K2_WORDS_PER_BLOCK];
     __shared__ int s_total;
 
-    // pixels kept before this block = sum of the earlier segments' counts (<= a few hundred ints)
-    const int32_t* sg = P.seg + bi * P.nseg;
+    // the image's foreground count (tn0) and the pixels kept before this block = sums over the segment counts
+    // (<= a few hundred ints)
+    const int32_t* sg = P.seg0 + bi * P.nseg;
     const bool last = blockIdx.x == gridDim.x - 1;
     if (!last && sg[blockIdx.x] == 0) return;  // block-uniform: most of the image is background
-    int part = 0;
-    for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) part += sg[j];
+    int part = 0, tot = 0;
+    for (int j = threadIdx.x; j < P.nseg; j += 256) {
+        const int c = sg[j];
+        tot += c;
+        part += j < (int)blockIdx.x ? c : 0;
+    }
     part = wave_reduce_add(part);
-    if (lane == 0) s_red[wave] = part;
-    if (wave == 0) {  // exclusive scan of this block's 64 word popcounts
-        const unsigned long long wd = (w0 + lane < P.words) ? bw[w0 + lane] : 0ull;
+    tot = wave_reduce_add(tot);
+    if (lane == 0) {
+        s_red[wave] = part;
+        s_tot[wave] = tot;
+    }
+    auto scan_words = [&](unsigned long long wd) {  // wave 0: exclusive scan of this block's 64 word popcounts
         const int c = __popcll(wd);
         int incl = c;
 #pragma unroll
@@ -427,9 +424,41 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
         s_word[lane] = wd;
         s_woff[lane] = incl - c;
         if (lane == 63) s_total = incl;
-    }
+    };
+    if (wave == 0) scan_words((w0 + lane < P.words) ? bw[w0 + lane] : 0ull);
     __syncthreads();
-    const int base = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    const int tn0 = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+    int base = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    if (tn0 > P.max_num) {
+        // Thinning (block-uniform, rare: objects larger than max_num pixels, or the evaluation call site's max_num = 100):
+        // keep a pixel when the top THIN_BITS bits of its random word are below k (oracle: subsample_threshold).  The pixels kept in
+        // earlier segments are column k - 1 of their cumulative histograms (K1); this segment's words are filtered here,
+        // 16 bits per thread.
+        const int k = (int)(((long long)THIN_BINS * P.max_num + tn0 - 1) / tn0);  // 0 .. THIN_BINS
+        int part2 = 0;
+        if (k > 0)
+            for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256)
+                if (sg[j] > 0) part2 += P.cum[((size_t)bi * P.nseg + j) * THIN_BINS + k - 1];
+        part2 = wave_reduce_add(part2);
+        const int q = threadIdx.x & 3;
+        unsigned todo = (unsigned)(s_word[threadIdx.x >> 2] >> (16 * q)) & 0xFFFFu, kept = 0;
+        const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_SUB, (uint32_t)(P.image_base + bi));
+        const uint32_t p0 = (uint32_t)((w0 + (threadIdx.x >> 2)) * 64 + 16 * q);
+        while (todo) {
+            const int bpos = __ffs((int)todo) - 1;
+            todo &= todo - 1;
+            if ((int)(pvnet_rng_at(key, p0 + (uint32_t)bpos) >> (32 - THIN_BITS)) < k) kept |= 1u << bpos;
+        }
+        __syncthreads();  // every read of s_word / s_red above has been performed
+        s_piece[threadIdx.x] = (uint16_t)kept;
+        if (lane == 0) s_red[wave] = part2;
+        __syncthreads();
+        if (wave == 0)
+            scan_words((unsigned long long)s_piece[4 * lane] | ((unsigned long long)s_piece[4 * lane + 1] << 16) |
+                       ((unsigned long long)s_piece[4 * lane + 2] << 32) | ((unsigned long long)s_piece[4 * lane + 3] << 48));
+        __syncthreads();
+        base = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    }
     const int usable = P.cap - PAD;
 
     // One thread per KEPT pixel (not per mask bit): thread t of the segment finds the word holding its pixel by a
@@ -501,11 +530,8 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
         const int total = base + s_total;
         const int tn = total < usable ? total : usable;
         if (k0 == 0 && wave == 0) {  // nothing zero-fills ctrl: this block owns tn0 / tn / status of its image
-            int t0 = 0;
-            for (int j = lane; j < P.nseg; j += 64) t0 += P.seg0[bi * P.nseg + j];
-            t0 = wave_reduce_add(t0);
             if (lane == 0) {
-                P.ctrl[bi * CTRL_STRIDE + C_TN0] = t0;
+                P.ctrl[bi * CTRL_STRIDE + C_TN0] = tn0;
                 P.ctrl[bi * CTRL_STRIDE + C_TN] = tn;
                 P.ctrl[bi * CTRL_STRIDE + C_STATUS] = total > usable ? PVNET_S_OVERFLOW : 0;
             }
@@ -1419,7 +1445,7 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
                int* score_grid = nullptr) {
     const bool literal = (P.flags & PVNET_F_LITERAL) != 0;
     auto mark = [&](int i) -> hipError_t { return ev ? hipEventRecord(ev[i], s) : hipSuccess; };
-    // bit i set = launch stage i (K1, K1b, K2, K3, K4, K5); a workspace left by a complete call stays valid, so single
+    // bit i set = launch stage i (K1, -, K2, K3, K4, K5; slot 1 is empty since round 2); a workspace left by a complete call stays valid, so single
     // stages can be re-run on it in isolation (pvnet_vote_v3_stage_repeat; development aid: PVNET_DEV_STAGES)
     const Tuning& T = tuning();
     const int stages = stage_mask >= 0 ? stage_mask : T.dev_stages;
@@ -1431,13 +1457,7 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
         }
         PV_LAUNCH_CHECK();
         PV_HIP(mark(1));
-        if ((stages & 2) && P.max_num < P.npix) {  // host-known: subsampling can only trigger when max_num < h*w
-            int bpi = (640 + P.b - 1) / P.b;  // blocks per image: a few hundred blocks in total, whatever the batch
-            bpi = bpi < K1B_BLOCKS ? K1B_BLOCKS : bpi;
-            bpi = bpi > P.nseg ? P.nseg : bpi;
-            hipLaunchKernelGGL(subsample_kernel, dim3(bpi, P.b), dim3(64 * K1B_WAVES), 0, s, P);
-            PV_LAUNCH_CHECK();
-        }
+        // (stage slot 1 was the thinning launch of round 1: the mask kernel's histograms + the compaction kernel do it now)
         PV_HIP(mark(2));
     }
     if (stages & 4) {   // K2
@@ -1548,6 +1568,9 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     P.items = reinterpret_cast<int4*>(base + L.off_items);
     P.seg = reinterpret_cast<int32_t*>(base + L.off_seg);
     P.seg0 = P.seg + (size_t)L.b * L.nseg;
+    P.cum = max_num < h * (long long)w
+                ? reinterpret_cast<uint16_t*>(base + L.off_seg + align_up(sizeof(int32_t) * 2 * (size_t)L.b * L.nseg, 16))
+                : nullptr;
     P.nseg = L.nseg;
     P.bits = reinterpret_cast<uint64_t*>(base + L.off_bits);
     P.pix = reinterpret_cast<int32_t*>(base + L.off_pix);
@@ -1578,8 +1601,9 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     if ((long long)hn * vn > (1ll << 24)) return PVNET_E_UNSUPPORTED;  // grid sizes and 32-bit indices
     const long long npix = (long long)h * w;
     long long cap = npix;
-    if (max_num < npix) {  // tn ~ Binomial(tn0, max_num/tn0): mean max_num, sigma <= sqrt(max_num); 8 sigma margin
-        const long long c = (long long)max_num + 8ll * (long long)ceil(sqrt((double)max_num)) + 64;
+    if (max_num < npix) {  // tn ~ Binomial(tn0, k / 1024), k = ceil(1024 max_num / tn0): mean < max_num + tn0 / 1024; 8 sigma
+        const long long mean = (long long)max_num + (npix + THIN_BINS - 1) / THIN_BINS;
+        const long long c = mean + 8ll * (long long)ceil(sqrt((double)mean)) + 64;
         cap = c < npix ? c : npix;
     }
     cap = (cap + PAD - 1) / PAD * PAD + PAD;
@@ -1616,7 +1640,10 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     L->nseg = (L->words + SEG_WORDS - 1) / SEG_WORDS;
     L->off_ctrl = take(sizeof(int32_t) * CTRL_STRIDE * (size_t)(b + 1));
-    L->off_seg = take(sizeof(int32_t) * 2 * (size_t)b * L->nseg);  // thinned counts, then the mask's own
+    // [2][b][nseg] int32 (the second array holds the mask's segment counts; the first is unused since round 2), then,
+    // when thinning is possible (max_num < h*w), the segments' cumulative histograms uint16 [b][nseg][THIN_BINS]
+    L->off_seg = take(align_up(sizeof(int32_t) * 2 * (size_t)b * L->nseg, 16) +
+                      (max_num < npix ? sizeof(uint16_t) * THIN_BINS * (size_t)b * L->nseg : 0));
     L->off_items = take(sizeof(int32_t) * 4 * (size_t)b * vn * (hgroups / wg_g) *
                         (size_t)((L->max_chunks + L->wg_s - 1) / L->wg_s));
     L->off_bits = take(sizeof(uint64_t) * (size_t)b * L->words);

@@ -92,7 +92,7 @@ def load_library() -> C.CDLL:
     lib.pvnet_vote_distribution.argtypes = [f32p, f32p] + ws_tail
     lib.pvnet_vote_tuning_reload.restype = None
     lib.pvnet_vote_tuning_reload.argtypes = []
-    if lib.pvnet_vote_abi_version() != 4:
+    if lib.pvnet_vote_abi_version() != 5:
         raise RuntimeError("pvnet_amd: libpvnet_vote.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib
@@ -307,7 +307,7 @@ def stage_repeat_ms(mask, vertex, round_hyp_num, inlier_thresh=0.999, min_num=5,
 
 class VotePlan:
     """A voting call of ONE shape prepared once: layout, workspace, output tensor and the ctypes argument block are
-    built here, so a repeated call costs one ctypes call (six kernel launches) and nothing else on the host -- the
+    built here, so a repeated call costs one ctypes call (five kernel launches) and nothing else on the host -- the
     reference's real call sites vote one image at a time (tools/demo.py:55: hn 512; tools/train_linemod.py:106:
     hn 128, max_num 100), where per-call host work is what the caller feels.
 

@@ -187,11 +187,49 @@ def test_max_num_subsample_matches_oracle():
                                          return_debug=True)
     for bi, d in enumerate(rdbg):
         tn = int(dbg["tn"][bi])
-        assert tn == d["tn"] and 200 < tn < 400 < d["tn0"]  # Bernoulli(max_num/tn0), same counter RNG
+        assert tn == d["tn"] and 200 < tn < 400 < d["tn0"]  # Bernoulli(ceil(1024 max_num / tn0) / 1024), same counter RNG
         pix = dbg["pix"][bi, :tn].cpu().numpy()
         np.testing.assert_array_equal(pix, (d["coords"][:, 1] * 160 + d["coords"][:, 0]).astype(np.int64))
         np.testing.assert_array_equal(dbg["win"][bi, :, 0].cpu().numpy(), d["win_idx"])
     assert np.abs(out.cpu().numpy() - ref).max() < 1e-4
+
+
+@pytest.mark.parametrize("max_num_of", ["tn0-1", "tn0//3", "97", "1", "0"])
+def test_thinning_without_its_own_launch_edge_cases(max_num_of):
+    """round 2: the thinning launch is gone -- the mask kernel leaves, per segment, the cumulative histogram of the top ten
+    bits of every foreground pixel's random word, and the compaction kernel picks column k - 1, k = ceil(1024 max_num / tn0)
+    (oracle: subsample_threshold).  Images of one batch with different tn0 (one below max_num: not thinned), objects that
+    span many 4096-pixel segments, k = 1024 (max_num = tn0 - 1: nothing is dropped although tn0 > max_num), k = 1 and
+    max_num = 0 (nothing kept): the kept-pixel LIST equals the oracle's, and so do winners and key-points."""
+    mask, planar, _ = synth.make_batch(3, first_index=905, h=200, w=260, radius=44, noise=True, background="normal")
+    mask[2] = 0
+    mask[2, 90:100, 100:130] = 1                                   # 300 pixels: below every max_num but the last three
+    vnp = synth.planar_to_vertex_view(planar)
+    tn0 = [int((mask[i] != 0).sum()) for i in range(3)]
+    max_num = {"tn0-1": tn0[0] - 1, "tn0//3": tn0[0] // 3, "97": 97, "1": 1, "0": 0}[max_num_of]
+    m, v = to_dev(mask, planar)
+    out, dbg = voting.ransac_voting_layer_v3(m, v, 96, inlier_thresh=0.99, seed=21, max_num=max_num, literal=True,
+                                             return_debug=True)
+    ref, rdbg = O.ransac_voting_layer_v3(mask, vnp, 96, inlier_thresh=0.99, seed=21, max_num=max_num, dtype=np.float32,
+                                         return_debug=True)
+    assert not (dbg["status"] & voting.S_OVERFLOW).any()
+    for bi, d in enumerate(rdbg):
+        assert int(dbg["tn0"][bi]) == tn0[bi]
+        if d["skipped"]:                                           # nothing kept (the reference would raise at :547): zeros
+            assert (out[bi] == 0).all() and int(dbg["tn"][bi]) == 0
+            continue
+        tn = int(dbg["tn"][bi])
+        assert tn == d["tn"]
+        if tn0[bi] > max_num:
+            k = -(-1024 * max_num // tn0[bi])
+            assert abs(tn - tn0[bi] * k / 1024) <= 6 * np.sqrt(tn0[bi] * k / 1024 + 1)   # Binomial(tn0, k / 1024)
+            assert tn0[bi] * k / 1024 < max_num + tn0[bi] / 1024 + 1e-9
+        else:
+            assert tn == tn0[bi]
+        np.testing.assert_array_equal(dbg["pix"][bi, :tn].cpu().numpy(), (d["coords"][:, 1] * 260 + d["coords"][:, 0]).astype(np.int64))
+        np.testing.assert_array_equal(dbg["win"][bi, :, 0].cpu().numpy(), d["win_idx"])
+    ok = np.isfinite(ref).all(-1) & (np.abs(ref) < 1e4).all(-1)
+    assert np.abs(out.cpu().numpy() - ref)[ok].max() < 1e-3
 
 
 @pytest.mark.parametrize("h,w,vn,hn", [(37, 53, 1, 100), (64, 64, 3, 33), (50, 200, 9, 520)])
@@ -443,7 +481,8 @@ def test_tiny_masks_and_many_keypoints():
 
 
 def test_full_frame_foreground_is_subsampled_to_max_num():
-    """480x640 all foreground, max_num = 30000 (the reference default): Bernoulli thinning on the device, no overflow."""
+    """480x640 all foreground, max_num = 30000 (the reference default): Bernoulli thinning on the device (75 segments, every
+    compaction block reads the earlier segments' histogram columns), no overflow."""
     h, w = 480, 640
     kp = np.array([[100.5, 200.25], [500.0, 50.0], [320.0, 240.0]])
     fg = np.ones((h, w), bool)
