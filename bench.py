@@ -526,7 +526,7 @@ def main(argv=None):
                              "path_ms_serial": path_s * 1e3,
                              "note": f"compulsory {compulsory / 1e6:.0f} MB, measured {(measured or 0) / 1e6:.0f} MB per batch; "
                                      "compulsory = int64 masks + foreground vectors (what must cross HBM); measured = "
-                                     "rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the six kernels (committed PMC pass); "
+                                     "rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the five kernels (committed PMC pass); "
                                      "dense_equivalent = SURVEY 8d's 24 576 072 B per voting, the bytes a dense "
                                      "implementation streams -- NOT achieved bandwidth: the path never reads the "
                                      "background of the field.  All three over the multi-stream step time."},
