@@ -144,6 +144,9 @@ __global__ __launch_bounds__(256) void compact_kernel(Params P) {
             emit(pos1, x1, y1, ux1, uy1);
         }
     }
+#ifdef V_ENDSYNC
+    __syncthreads();  // all waves of a workgroup end together
+#endif
 }
 #ifndef DYNLDS
 #define DYNLDS 0
