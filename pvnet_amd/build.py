@@ -56,14 +56,66 @@ def build_pnp(force: bool = False, verbose: bool = False) -> str:
     return PNP_LIB
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    build_pnp(force, verbose)
-    if not force and up_to_date():
-        return LIB
-    cmd = [hipcc_path()] + flags() + SRC + ["-o", LIB]
+# the reference's compiled extension module `ransac_voting` (src/ransac_voting.cpp) on this library: host-only C++ against
+# the torch headers, placed where the reference's driver imports it from
+EXT_SRC = os.path.join(HERE, "csrc", "ransac_voting_ext.cpp")
+EXT_DIR = os.path.join(ROOT, "lib", "ransac_voting_gpu_layer")
+
+
+def ext_path() -> str:
+    import sysconfig
+    return os.path.join(EXT_DIR, "ransac_voting" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_ext(force: bool = False, verbose: bool = False):
+    """g++ -> lib/ransac_voting_gpu_layer/ransac_voting<EXT_SUFFIX> (linked against libpvnet_vote.so through an
+    $ORIGIN-relative rpath).  Returns the path, or None when torch's headers / a C++ compiler are not available -- the
+    pure-Python stand-in of the same name next to it serves the same four functions then."""
+    import sysconfig
+    out = ext_path()
+    deps = [EXT_SRC, os.path.join(ROOT, "include", "pvnet_vote.h"), LIB]
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
+        return out
+    cxx = os.environ.get("CXX") or shutil.which("g++") or shutil.which("c++")
+    try:
+        import torch
+        from torch.utils import cpp_extension
+    except Exception:
+        return None
+    if not cxx:
+        return None
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    inc = cpp_extension.include_paths() + [os.path.join(rocm, "include"), os.path.join(ROOT, "include"),
+                                           sysconfig.get_paths()["include"]]
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_EXTENSION_NAME=ransac_voting", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    for i in inc:
+        cmd += ["-I", i]
+    cmd += [EXT_SRC, "-o", out, "-L", tlib, "-L", HERE, "-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu", "-ltorch_hip",
+            "-ltorch_python", "-lpvnet_vote", "-Wl,-rpath," + tlib, "-Wl,-rpath,$ORIGIN/../../pvnet_amd"]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+    except (subprocess.CalledProcessError, OSError) as e:
+        if os.path.exists(out):
+            os.remove(out)
+        print(f"pvnet_amd.build: the compiled ransac_voting module was not built ({e}); the Python stand-in serves it",
+              file=sys.stderr)
+        return None
+    return out
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    build_pnp(force, verbose)
+    if force or not up_to_date():
+        cmd = [hipcc_path()] + flags() + SRC + ["-o", LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    build_ext(force, verbose)
     return LIB
 
 

@@ -5,6 +5,8 @@ MI355X next to our kernels on identical device buffers.
 
 This pins the chain: reference kernels == plain-C restatement == numpy float32 oracle == HIP literal mode, all
 bit-exact; the default fast mode is then measured against the reference kernels' inlier sets."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -115,9 +117,55 @@ def test_vanishing_point_ops_equal_reference_device_code():
         voting.generate_hypothesis_vanishing_point(d.cpu(), c, i)
     with pytest.raises(RuntimeError):
         voting.voting_for_hypothesis_vanishing_point(d, c, h2[:, :, :2], mine, 0.99)
-    import lib.ransac_voting_gpu_layer.ransac_voting as ext      # the module name the reference's driver imports (:2)
-    assert ext.generate_hypothesis_vanishing_point is voting.generate_hypothesis_vanishing_point
-    assert ext.voting_for_hypothesis_vanishing_point is voting.voting_for_hypothesis_vanishing_point
+    import lib.ransac_voting_gpu_layer.ransac_voting as ext      # the module name the reference's driver imports (:2):
+    # the compiled extension (pvnet_amd/csrc/ransac_voting_ext.cpp) when it was built, else the Python stand-in
+    got = ext.generate_hypothesis_vanishing_point(d, c, i)
+    assert got.cpu().numpy().tobytes() == hyp_c.tobytes()
+    again = torch.zeros((hn, 9, tn), dtype=torch.uint8, device=dev())
+    ext.voting_for_hypothesis_vanishing_point(d, c, h2, again, 0.99)
+    assert torch.equal(again, refkernels.voting_for_hypothesis_vanishing_point(d, c, h2, 0.99))
+
+
+def test_compiled_extension_module_equals_reference_device_code():
+    """the reference's plugin is a COMPILED module (`ransac_voting`, src/ransac_voting.cpp: four pybind functions); so is
+    ours (pvnet_amd/csrc/ransac_voting_ext.cpp on libpvnet_vote.so, built into the directory the reference's driver imports
+    it from).  Same calls, same in/out conventions, same CHECK_INPUT errors -- and bit-equal results with the reference's own
+    device code on the MI355X."""
+    from pvnet_amd import build as B
+    import importlib
+    if not os.path.exists(B.ext_path()):
+        pytest.skip("compiled ransac_voting module not built (python -m pvnet_amd.build)")
+    ext = importlib.import_module("lib.ransac_voting_gpu_layer.ransac_voting")
+    assert ext.__file__ == B.ext_path() and "pvnet_amd" in ext.backend      # the extension module shadows the .py stand-in
+    _, _, coords, direct = compacted(first=655, h=130, w=170, radius=17)
+    tn = coords.shape[0]
+    hn = 80
+    idxs = np.random.default_rng(8).integers(0, tn, (hn, 9, 2), dtype=np.int32)
+    d, c, i = (torch.from_numpy(x).to(dev()) for x in (direct, coords, idxs))
+    hyp = ext.generate_hypothesis(d, c, i)                                  # ransac_voting_gpu.py:554
+    assert hyp.dtype == torch.float32 and hyp.shape == (hn, 9, 2)
+    assert torch.equal(hyp, refkernels.generate_hypothesis(d, c, i))
+    inl = torch.zeros((hn, 9, tn), dtype=torch.uint8, device=dev())         # :555-556: zeros, then the op sets ones
+    inl[3, 1, 5] = 9
+    assert ext.voting_for_hypothesis(d, c, hyp, inl, 0.99) is None
+    want = refkernels.voting_for_hypothesis(d, c, hyp, 0.99)
+    want[3, 1, 5] = 1 if int(want[3, 1, 5]) else 9
+    assert torch.equal(inl, want)
+    # on a side stream (the reference launches on the legacy default stream; this module uses the current one)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        hyp2 = ext.generate_hypothesis(d, c, i)
+    st.synchronize()
+    assert torch.equal(hyp2, hyp)
+    # CHECK_INPUT (ransac_voting.cpp:7-9) and the dtype / shape checks
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        ext.generate_hypothesis(d.cpu(), c, i)
+    with pytest.raises(RuntimeError, match="must be contiguous"):
+        ext.generate_hypothesis(d.transpose(0, 1).contiguous().transpose(0, 1), c, i)
+    with pytest.raises(RuntimeError, match="int32"):
+        ext.generate_hypothesis(d, c, i.long())
+    with pytest.raises(RuntimeError):
+        ext.voting_for_hypothesis(d, c, hyp, inl[:, :, :-1].contiguous(), 0.99)
 
 
 @pytest.mark.parametrize("hn,thresh", [(128, 0.99), (256, 0.999)])
