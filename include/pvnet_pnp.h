@@ -47,6 +47,15 @@ int pvnet_pnp_solve_batch(const double* pts2d, const double* pts3d, const double
 void pvnet_angle_axis_to_matrix(const double* aa, double* R);
 void pvnet_matrix_to_angle_axis(const double* R, double* aa);
 
+/* Farthest-point sampling under the reference's own C symbols (src/utils_python_binding.h, implemented in
+ * src/farthest_point_sampling.cpp:178-221; called through cffi by extend_utils.py:22-37 -- the reference chooses its 8 object
+ * key-points with it, lib/utils/data_utils.py:144).  pts [pn,3] float32, idxs [sn] int32 receives the selected indices in
+ * selection order.  `_init_center` is deterministic (first point = farthest from the bounding-box centre, whose distances
+ * also seed every point's nearest-selected distance); the plain one starts at a random point.  Float32 squared distances in
+ * the reference's operation order; strict `>` from index 0 on ties. */
+void farthest_point_sampling(float* pts, int* idxs, int pn, int sn);
+void farthest_point_sampling_init_center(float* pts, int* idxs, int pn, int sn);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,10 @@
 // Plain C++17, no dependencies; built by pvnet_amd/build.py with g++.
 #include "pvnet_pnp.h"
 
+#include <cfloat>
 #include <cmath>
+#include <cstdlib>
+#include <ctime>
 #include <cstring>
 
 namespace {
@@ -377,6 +380,72 @@ void pvnet_matrix_to_angle_axis(const double* R, double* aa) {
     const double sn = std::sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     const double k = sn < 1e-12 ? 2.0 : 2.0 * std::atan2(sn, q[0]) / sn;
     aa[0] = k * q[1]; aa[1] = k * q[2]; aa[2] = k * q[3];
+}
+
+// ---- farthest-point sampling (lib/utils/extend_utils/src/farthest_point_sampling.cpp:41-176): the reference picks its 8
+// object key-points with it (lib/utils/data_utils.py:144: farthest_point_sampling(pts, 8, True)).  Greedy: every point keeps
+// the squared distance (float32, x*x + y*y + z*z in that order) to the nearest point selected so far; the next selection is
+// the unselected point with the LARGEST such distance, the first one on ties (strict >, from index 0, start value 0).
+static int fps_next(const float* min_dist, const unsigned char* taken, int pn) {
+    int best = 0;
+    float best_d = 0.f;
+    for (int i = 0; i < pn; ++i)
+        if (!taken[i] && min_dist[i] > best_d) {
+            best = i;
+            best_d = min_dist[i];
+        }
+    return best;
+}
+
+static void fps_run(const float* pts, int* idxs, int pn, int sn, float* min_dist, unsigned char* taken, int cur) {
+    for (int s = 0; s < sn; ++s) {
+        taken[cur] = 1;
+        idxs[s] = cur;
+        if (s == sn - 1) break;
+        const float cx = pts[cur * 3], cy = pts[cur * 3 + 1], cz = pts[cur * 3 + 2];
+        for (int i = 0; i < pn; ++i) {
+            if (taken[i]) continue;
+            const float dx = pts[i * 3] - cx, dy = pts[i * 3 + 1] - cy, dz = pts[i * 3 + 2] - cz;
+            const float d = dx * dx + dy * dy + dz * dz;
+            if (d < min_dist[i]) min_dist[i] = d;
+        }
+        cur = fps_next(min_dist, taken, pn);
+    }
+}
+
+// starts from a random point (the reference seeds rand() with the wall clock: farthest_point_sampling.cpp:96-97)
+void farthest_point_sampling(float* pts, int* idxs, int pn, int sn) {
+    if (!pts || !idxs || pn <= 0 || sn <= 0) return;
+    float* min_dist = new float[pn];
+    unsigned char* taken = new unsigned char[pn]();
+    for (int i = 0; i < pn; ++i) min_dist[i] = FLT_MAX;
+    std::srand((unsigned)std::time(nullptr));
+    fps_run(pts, idxs, pn, sn, min_dist, taken, std::rand() % pn);
+    delete[] min_dist;
+    delete[] taken;
+}
+
+// deterministic: distances start as those to the centre of the bounding box, the first point is the one farthest from it
+// (farthest_point_sampling.cpp:124-160)
+void farthest_point_sampling_init_center(float* pts, int* idxs, int pn, int sn) {
+    if (!pts || !idxs || pn <= 0 || sn <= 0) return;
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = 0; i < pn; ++i)
+        for (int a = 0; a < 3; ++a) {
+            hi[a] = pts[i * 3 + a] > hi[a] ? pts[i * 3 + a] : hi[a];
+            lo[a] = pts[i * 3 + a] < lo[a] ? pts[i * 3 + a] : lo[a];
+        }
+    const float half = 1.f / 2.f;  // (max + min) / 2 as a multiplication by the reciprocal, like the reference's operator/
+    const float cx = (hi[0] + lo[0]) * half, cy = (hi[1] + lo[1]) * half, cz = (hi[2] + lo[2]) * half;
+    float* min_dist = new float[pn];
+    unsigned char* taken = new unsigned char[pn]();
+    for (int i = 0; i < pn; ++i) {
+        const float dx = pts[i * 3] - cx, dy = pts[i * 3 + 1] - cy, dz = pts[i * 3 + 2] - cz;
+        min_dist[i] = dx * dx + dy * dy + dz * dz;
+    }
+    fps_run(pts, idxs, pn, sn, min_dist, taken, fps_next(min_dist, taken, pn));
+    delete[] min_dist;
+    delete[] taken;
 }
 
 }  // extern "C"

@@ -41,7 +41,8 @@ def test_host_pnp_library_exports_every_declared_symbol():
     body = hdr[hdr.index('extern "C"'):]
     names = set(re.findall(r"^(?:void|int)\s+([a-z0-9_]+)\s*\(", body, flags=re.M))
     assert {"uncertainty_pnp", "pvnet_pnp_refine", "pvnet_pnp_solve", "pvnet_pnp_solve_batch",
-            "pvnet_angle_axis_to_matrix", "pvnet_matrix_to_angle_axis"} == names
+            "pvnet_angle_axis_to_matrix", "pvnet_matrix_to_angle_axis", "farthest_point_sampling",
+            "farthest_point_sampling_init_center"} == names
     for n in names:
         assert hasattr(plib, n), f"{n} declared in include/pvnet_pnp.h but not exported"
 

@@ -66,6 +66,65 @@ def test_probe_leaves_the_reference_tree_clean():
     assert not fresh, fresh
 
 
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "lib", "utils", "extend_utils")), reason="needs the reference checkout")
+def test_reference_extend_utils_and_evaluation_utils_run_unchanged_on_the_native_libraries():
+    """the downstream callers: the reference's own lib/utils/extend_utils/extend_utils.py (cffi front end) and
+    lib/utils/evaluation_utils.py, byte for byte, on this repository's stand-in for the cffi-built `_extend_utils`
+    (lib/utils/extend_utils/_extend_utils.py: uncertainty_pnp / farthest_point_sampling in libpvnet_pnp.so) -- key-point
+    selection as data_utils.py:144 does it, `pnp`, `uncertainty_pnp`, `uncertainty_pnp_v2`."""
+    from oracle import fps_oracle
+    from pvnet_amd import pnp as P
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    txt = subprocess.check_output([sys.executable, "-B", os.path.join(ROOT, "tools", "reference_extend_utils_probe.py"), REF],
+                                  cwd="/tmp", env=env, stderr=subprocess.DEVNULL, timeout=600)
+    got = json.loads(txt)
+    assert got["extend_utils"].startswith(REF) and got["stand_in"].startswith(ROOT)
+    rng = np.random.default_rng(5)                                   # the probe's inputs, regenerated
+    model = rng.normal(size=(2000, 3)).astype(np.float32) * np.array([0.05, 0.03, 0.08], np.float32)
+    idx = fps_oracle.farthest_point_sampling_init_center(model, 8)
+    np.testing.assert_array_equal(np.asarray(got["fps_points"], np.float32), model[idx])
+    X3, x2 = np.asarray(got["inputs"]["X3"]), np.asarray(got["inputs"]["x2"])
+    W, cov = np.asarray(got["inputs"]["W"]), np.asarray(got["inputs"]["cov"])
+    K, true = P.LINEMOD_K, np.asarray(got["pose_true"])
+    for name, mine in (("pnp", P.pnp(X3, x2, K)), ("uncertainty_pnp", P.uncertainty_pnp(x2, W, X3, K)),
+                       ("uncertainty_pnp_v2", P.uncertainty_pnp_v2(x2, cov, X3, K))):
+        theirs = np.asarray(got[name])
+        assert np.abs(theirs - mine).max() < 1e-6, name             # same minimum of the same cost, whatever the start
+        tr, rot = P.cm_degree_error(theirs, true)
+        assert tr < 3.0 and rot < 3.0, (name, tr, rot)              # 0.4 px of key-point noise at 0.9 m
+
+
+def test_farthest_point_sampling_equals_oracle_and_the_references_own_source():
+    """libpvnet_pnp.so `farthest_point_sampling_init_center` (the reference's C symbol, include/pvnet_pnp.h) == numpy float32
+    restatement == the reference's own farthest_point_sampling.cpp compiled where it lies (oracle/_ref, when built)."""
+    import ctypes as C
+    from oracle import fps_oracle
+    import importlib
+    stand_in = importlib.import_module("lib.utils.extend_utils._extend_utils")
+    rng = np.random.default_rng(11)
+    for pn, sn in ((500, 8), (64, 64), (3000, 33), (10, 4)):
+        pts = rng.normal(size=(pn, 3)).astype(np.float32)
+        pts[pn // 2] = pts[0]                                       # a duplicate point: ties and zero distances
+        idxs = np.zeros(sn, np.int32)
+        stand_in.lib.farthest_point_sampling_init_center(stand_in.ffi.cast("float*", pts.ctypes.data),
+                                                         stand_in.ffi.cast("int*", idxs.ctypes.data), pn, sn)
+        np.testing.assert_array_equal(idxs, fps_oracle.farthest_point_sampling_init_center(pts, sn))
+        if fps_oracle.reference_available():
+            np.testing.assert_array_equal(idxs, fps_oracle.reference_init_center(pts, sn))
+        if sn < pn // 2:
+            assert len(set(idxs.tolist())) == sn
+    # the random-start variant: sn distinct indices, spread out (every selected pair farther apart than the cloud's median)
+    pts = rng.normal(size=(400, 3)).astype(np.float32)
+    idxs = np.zeros(6, np.int32)
+    stand_in.lib.farthest_point_sampling(stand_in.ffi.cast("float*", pts.ctypes.data), stand_in.ffi.cast("int*", idxs.ctypes.data), 400, 6)
+    assert len(set(idxs.tolist())) == 6 and (idxs >= 0).all() and (idxs < 400).all()
+    sel = pts[idxs]
+    d = np.linalg.norm(sel[:, None] - sel[None], axis=-1)[np.triu_indices(6, 1)]
+    assert d.min() > np.median(np.linalg.norm(pts[:, None] - pts[None], axis=-1))
+    with pytest.raises(NotImplementedError):
+        stand_in.lib.mesh_binary_rasterization(None, None, 0, 0, 0)
+
+
 # ------------------------------------------------------------------------------------------------------------ GPU
 def _demo_inputs(demo_fixture, dev):
     from pvnet_amd import synth
@@ -135,3 +194,22 @@ def test_reference_wrappers_on_the_hip_layer(demo_fixture):
     pose = P.pnp(demo_fixture["points_3d"], outs["demo.EvalWrapper"][0][0].astype(np.float64), demo_fixture["K"])
     tr_cm, rot_deg = P.cm_degree_error(pose, demo_fixture["pose"].astype(np.float64))
     assert tr_cm < 0.05 and rot_deg < 0.1
+
+
+@pytest.mark.gpu
+def test_nearest_neighbour_through_the_cffi_stand_in():
+    """extend_utils.py:39-60 as the reference writes it -- host arrays, `ffi.cast`, `lib.findNearestPointIdxLauncher` -- on the
+    stand-in for `_extend_utils`: the HIP brute-force search behind the reference's own launcher symbol."""
+    import importlib
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    m = importlib.import_module("lib.utils.extend_utils._extend_utils")
+    lib, ffi = m.lib, m.ffi
+    rng = np.random.default_rng(3)
+    for dim in (3, 2):
+        ref_pts = np.ascontiguousarray(rng.normal(size=(1, 1500, dim)), np.float32)
+        que_pts = np.ascontiguousarray(rng.normal(size=(1, 1200, dim)), np.float32)
+        idxs = np.zeros([1, 1200], np.int32)
+        lib.findNearestPointIdxLauncher(ffi.cast('float *', ref_pts.ctypes.data), ffi.cast('float *', que_pts.ctypes.data),
+                                        ffi.cast('int *', idxs.ctypes.data), 1, 1500, 1200, dim, 0)
+        d = ((que_pts[0][:, None, :] - ref_pts[0][None, :, :]) ** 2).sum(-1)
+        np.testing.assert_array_equal(idxs[0], d.argmin(1))

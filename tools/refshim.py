@@ -149,11 +149,8 @@ def install(reference_root=None):
     for n in ("imread", "imsave", "imresize"):
         if not hasattr(sm, n):
             setattr(sm, n, _Anything(f"scipy.misc.{n}"))
-    # the cffi-built extension `lib.utils.extend_utils._extend_utils` (Ceres + CUDA inside; extend_utils.py:3)
-    name = "lib.utils.extend_utils._extend_utils"
-    if name not in sys.modules:
-        ext = _StubModule(name)
-        sys.modules[name] = ext
+    # (the cffi-built extension `lib.utils.extend_utils._extend_utils` -- Ceres + CUDA inside, extend_utils.py:3 -- is not
+    # stubbed: this repository's overlay tree carries a real stand-in of that name on its native libraries)
     return roots
 
 
@@ -168,12 +165,36 @@ def _wire_cv2(cv2):
             return P.rodrigues(x.reshape(3)), None
         return P.rodrigues_inv(x.reshape(3, 3)).reshape(3, 1), None
 
-    def solvePnP(points_3d, points_2d, camera_matrix, dist_coeffs, flags=None, **kw):
+    def solvePnP(objectPoints, imagePoints, cameraMatrix, distCoeffs=None, rvec=None, tvec=None, useExtrinsicGuess=False,
+                 flags=0, **kw):
+        """cv2's argument list (the reference passes rvec / tvec / useExtrinsicGuess positionally, extend_utils.py:90-92).
+        >= 6 points: this repository's pnp (linear start + LM).  4-5 points (the reference's SOLVEPNP_P3P start on the four
+        best-weighted key-points): LM on the reprojection error from a fan of initial poses in front of the camera, the
+        lowest cost wins -- only ever used as the start of the all-points refinement."""
         from pvnet_amd import pnp as P
-        pose = P.pnp(np.asarray(points_3d, np.float64).reshape(-1, 3), np.asarray(points_2d, np.float64).reshape(-1, 2),
-                     np.asarray(camera_matrix, np.float64))
-        rvec = P.rodrigues_inv(pose[:, :3]).reshape(3, 1)
-        return True, rvec, pose[:, 3].reshape(3, 1)
+        p3 = np.asarray(objectPoints, np.float64).reshape(-1, 3)
+        p2 = np.asarray(imagePoints, np.float64).reshape(-1, 2)
+        K = np.asarray(cameraMatrix, np.float64)
+        if p3.shape[0] >= 6:
+            pose = P.pnp(p3, p2, K)
+            return True, P.rodrigues_inv(pose[:, :3]).reshape(3, 1), pose[:, 3].reshape(3, 1)
+        size = np.linalg.norm(p3.max(0) - p3.min(0)) + 1e-12
+        spread = np.linalg.norm(p2.max(0) - p2.min(0)) + 1e-12
+        z0 = K[0, 0] * size / spread
+        centre = np.linalg.solve(K, np.array([*p2.mean(0), 1.0])) * z0 - 0.0
+        best = None
+        for ax in np.eye(3):
+            for ang in np.linspace(0, 2 * np.pi, 8, endpoint=False):
+                for tilt in (0.0, 1.2, -1.2):
+                    aa = ax * ang + np.roll(ax, 1) * tilt
+                    R0 = P.rodrigues(aa)
+                    x0 = np.concatenate([P.rodrigues_inv(R0), centre - R0 @ p3.mean(0)])
+                    x = P._refine(x0, p3, p2, K, None, "native")
+                    cost = float((P._residuals(x, p3, p2, K) ** 2).sum())
+                    if np.isfinite(cost) and (best is None or cost < best[1]) and (P.rodrigues(x[:3]) @ p3.mean(0) + x[3:])[2] > 0:
+                        best = (x, cost)
+        x = best[0]
+        return True, np.asarray(x[:3], np.float64).reshape(3, 1), np.asarray(x[3:], np.float64).reshape(3, 1)
 
     cv2.Rodrigues = Rodrigues
     cv2.solvePnP = solvePnP
