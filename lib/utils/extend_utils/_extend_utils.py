@@ -10,7 +10,8 @@ here on ctypes (cffi is not needed), bound to this repository's native libraries
     farthest_point_sampling[_init_center]   libpvnet_pnp.so
     findNearestPointIdxLauncher             libpvnet_vote.so  (HIP brute-force nearest neighbour, include/pvnet_nn.h;
                                                               host pointers in and out as the reference's launcher; needs a GPU)
-    mesh_binary_rasterization               not provided (rendering / data synthesis: out of scope)
+    mesh_binary_rasterization, anything else not provided (rendering / data synthesis: out of scope, SURVEY.md section 2);
+                                            delegated to the checkout's own cffi-built module when it has one
 
 With this file ahead of the reference checkout on sys.path (the `lib` packages are namespace packages: the two trees
 merge), the reference's own `lib/utils/extend_utils/extend_utils.py` and `lib/utils/evaluation_utils.py` run unchanged on
@@ -79,7 +80,45 @@ class _Lib:
                                                      int(exclude_self))
 
     def mesh_binary_rasterization(self, *a):
-        raise NotImplementedError("mesh_binary_rasterization (rendering) is out of scope of this layer -- SURVEY.md section 2")
+        up = _upstream()
+        if up is not None:  # the user's checkout has its own cffi-built module: rendering stays with it
+            return up.lib.mesh_binary_rasterization(*a)
+        raise NotImplementedError("mesh_binary_rasterization (rendering) is out of scope of this layer -- SURVEY.md section 2 "
+                                  "-- and no cffi-built _extend_utils of a zju3dv/pvnet checkout was found on sys.path")
+
+    def __getattr__(self, name):  # anything else the reference's header may declare (render_depth_cffi, ...)
+        if name.startswith("_"):
+            raise AttributeError(name)
+        up = _upstream()
+        if up is not None and hasattr(up.lib, name):
+            return getattr(up.lib, name)
+        raise AttributeError(f"_extend_utils.lib.{name}: not provided by the MI355X stand-in and no cffi-built module found")
+
+
+_up = False
+
+
+def _upstream():
+    """the reference's own cffi-built `_extend_utils` extension module, if a checkout further down sys.path has one"""
+    global _up
+    if _up is False:
+        _up = None
+        import importlib.machinery
+        import importlib.util
+        here = os.path.dirname(os.path.abspath(__file__))
+        for root in sys.path:
+            d = os.path.join(root or ".", "lib", "utils", "extend_utils")
+            if not os.path.isdir(d) or os.path.abspath(d) == here:
+                continue
+            for suffix in importlib.machinery.EXTENSION_SUFFIXES:
+                cand = os.path.join(d, "_extend_utils" + suffix)
+                if os.path.exists(cand):
+                    spec = importlib.util.spec_from_file_location("lib.utils.extend_utils._extend_utils_upstream", cand)
+                    mod = importlib.util.module_from_spec(spec)
+                    spec.loader.exec_module(mod)
+                    _up = mod
+                    return _up
+    return _up
 
 
 ffi = _FFI()
