@@ -1721,6 +1721,7 @@ int pvnet_vote_v3_profiled(const void* mask, int mask_dtype, const int64_t mask_
             float ms = 0.f;
             e = hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
             stage_ms[i] = (e == hipSuccess) ? ms : -1.f;
+            if (i == PVNET_STAGE_SUBSAMPLE) stage_ms[i] = 0.f;  // an empty slot since ABI 5 (two event records back to back)
         }
     for (int i = 0; i <= PVNET_NUM_STAGES; ++i) (void)hipEventDestroy(ev[i]);
     return rc;
