@@ -21,6 +21,9 @@ __device__ __forceinline__ int wave_reduce_add(int v) {
 #endif
 template <int K2_KG>
 __global__ __launch_bounds__(256) void compact_kernel(Params P) {
+#ifdef V_SPARE
+    asm volatile("" ::: "v31");  // the rule: one unused VGPR granule beyond what the kernel uses (24 -> 32 allocated)
+#endif
 #ifdef V_SWAPYZ
     const int bi = blockIdx.z;
 #else

@@ -1,6 +1,6 @@
 """Development aid: random configurations, literal HIP path vs the C oracle (winners and counts must be exact) and fast
 vs literal (counts within 2 votes up to thresh 0.999), with the launch knobs flipped at random.
-    python tools/fuzz_parity.py [cases]   (MI355X)"""
+    python tools/fuzz_parity.py [cases [first_case]]   (MI355X)"""
 import os
 import sys
 
@@ -13,11 +13,12 @@ from pvnet_amd import synth, voting  # noqa: E402
 
 dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+START = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # first case (cases are seeded by their number)
 KNOBS = {"PVNET_SCORE_XCD": ["0", "1"], "PVNET_SCORE_ATOMIC": ["0", "1"], "PVNET_SCORE_WGS_PER_CU": ["0", "2", "8"],
          "PVNET_COMPACT_KG": ["1", "3", "9"]}
 bad = 0
 worst = {}
-for case in range(N):
+for case in range(START, N):
     rng = np.random.default_rng(5000 + case)
     for k, vals in KNOBS.items():
         os.environ[k] = str(rng.choice(vals))
@@ -50,7 +51,11 @@ for case in range(N):
     cd = int((df["counts"] - counts_l).abs().max())
     worst[thresh] = max(worst.get(thresh, 0), cd)
     fin = bool(torch.isfinite(fast).all())
-    lim = 2 if thresh <= 0.999 else 12  # (fast vs literal drift apart as thresh -> 1: the reference's float32 cos is flat there)
+    # fast vs literal drift apart as thresh -> 1 (the reference's float32 cos is flat there) and with the number of pixels a
+    # hypothesis is tested on: at 0.999 and 30 000 pixels literal is off by up to 3 votes against float64 arithmetic where fast is
+    # off by 0-1 (tools/experiments/fuzz_case_check.py 1046)
+    tn_max = int(df["tn"].max())
+    lim = 2 if thresh <= 0.99 else (2 + tn_max // 10000 if thresh <= 0.999 else 12)
     if not ok or cd > lim or not fin:
         bad += 1
         print("MISMATCH case", case, dict(h=h, w=w, vn=vn, hn=hn, b=b, radius=radius, thresh=thresh, max_num=max_num, mdt=mdt,
