@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PVNET_VOTE_ABI_VERSION 5
+#define PVNET_VOTE_ABI_VERSION 6
 
 /* negative library error codes */
 #define PVNET_E_BADARG      (-1)   /* null pointer / non-positive size / unsupported dtype or stride */
@@ -45,9 +45,16 @@ extern "C" {
 
 /* flags */
 #define PVNET_F_LITERAL   1u       /* score with the reference's float32 operation order (sqrt + divide, one
-                                      rounding per op): bit-exact with oracle32 and with the reference's own
-                                      kernels.  Default: |d x u| < tan(acos(thresh)) * (d . u) evaluated as two
-                                      bf16x3 MFMAs + compare (pvnet_vote.hip: score_mfma_kernel), fp32-equivalent */
+                                      rounding per op) on the VALU for EVERY (pixel, hypothesis) pair: bit-exact with
+                                      oracle32 and with the reference's own kernels, ~10x slower.
+                                      DEFAULT (neither this flag nor PVNET_F_APPROX; "exact mode", ABI 6): the same
+                                      integers -- inlier counts and winners EQUAL the reference kernels' -- at matrix-
+                                      pipe speed: every pair is tested as |d x u| < tan(acos(thresh)) * (d . u) by two
+                                      bf16x3 MFMAs, the margin leaves the MFMA epilogue through a saturating ramp whose
+                                      width is the provable float32 rounding band of ransac_voting_kernel.cu:107-125
+                                      plus the matrix pipe's own error, and only the cells that hold a pair INSIDE the
+                                      band (~1e-5 of the pairs at thresh 0.99) are re-evaluated in the reference's
+                                      operation order (pvnet_vote.hip: score_exact_kernel) */
 #define PVNET_F_NO_REFINE 2u       /* skip ransac_voting_gpu.py:579-595, return the winning hypotheses */
 /* element type of `vertex` (and, for pvnet_vote_v3_logits, of `seg_pred`) when it is not float32 -- what a backbone under
  * autocast emits.  The pointer is passed through the `const float*` parameter and read as the flagged type; strides stay
@@ -57,6 +64,14 @@ extern "C" {
 #define PVNET_F_VERTEX_BF16  8u
 #define PVNET_F_LOGITS_F16  16u
 #define PVNET_F_LOGITS_BF16 32u
+#define PVNET_F_APPROX      64u     /* the round-1/2 "fast" mode: matrix-pipe scoring WITHOUT the rounding-band rescoring.
+                                      Counts are those of exact arithmetic to within the fp32-equivalent error of the
+                                      bf16x3 products, i.e. they may differ from the reference's float32 kernels by a few
+                                      votes per hypothesis where the reference's own rounding decides a pair.  ~10 % faster
+                                      than the default; ignored with PVNET_F_LITERAL */
+
+#define PVNET_F_BAND_STATS 128u     /* development aid (exact mode): count the re-evaluated cells / literal tests into the two
+                                      spare words ctrl[b][4], ctrl[b][5] of the workspace (tools/band_stats.py) */
 
 /* per-(image,key-point) status bits written to out_status */
 #define PVNET_S_SKIPPED   1        /* fewer than min_num foreground pixels (or none kept): zeros returned */

@@ -98,6 +98,9 @@ struct VoteParams {
     int64_t vs0, vs1, vs2, vs3, vs4;
     int b, h, w, vn, hn, npix, words, cap, chunk, max_chunks, hpl, hgroups, hn_pad, wg_g, wg_s, mode, score_xcd, atomic_counts;
     float thresh, tau;
+    float kband;   // exact mode: half-width of the rounding band as a fraction of |d| |u| (band_constant())
+    int exact;     // 1: matrix-pipe scoring + literal re-evaluation of the cells that hold a pair inside the band
+    int fold1;     // exact mode: 1 = a cell is one pixel tile (16 tests per lane), 0 = the whole work item (band_fold1())
     int min_num, max_num;
     uint64_t seed;
     int image_base;
@@ -151,6 +154,13 @@ __device__ __forceinline__ bool inlier_literal(float cx, float cy, float nx, flo
     if (norm1 <= kF1e6 || norm2 <= kF1e6) return false;
     const float ang = (dx * nx + dy * ny) / (norm1 * norm2);
     return ang > thresh;
+}
+
+// the reference's norm1 (kernel.cu:119) in its operation order: the |u| < 1e-6 gate must fall exactly where the
+// reference's falls, because a record that fails it is stored as a zero record by the matrix-pipe modes
+__device__ __forceinline__ float norm1_literal(float nx, float ny) {
+#pragma clang fp contract(off)
+    return __builtin_sqrtf(nx * nx + ny * ny);
 }
 
 // Fast form of the same predicate.  With tau = sqrt(1 - thresh^2) / thresh (0 < thresh < 1) and d = h - c:
@@ -243,6 +253,83 @@ __device__ __forceinline__ void b_col(float x, float y, uint4& lo, uint4& hi) {
     const uint32_t one = 0x3F80u;
     lo = make_uint4(pk(x0, x0), pk(x1, x0), pk(x2, x1), pk(y0, y0));
     hi = make_uint4(pk(y1, y0), pk(y2, y1), pk(one, one), pk(one, 0u));
+}
+
+// ---- exact mode: the same two MFMAs, arranged so that the epilogue also sees how close every test is to the threshold
+// Goal: inlier counts EQUAL to the reference's float32 kernel (kernel.cu:107-125) at matrix-pipe speed.  The reference
+// decides  ang = fl(dot / (norm1 * norm2)) > thresh  with nine float32 roundings; against exact arithmetic on the same
+// float32 inputs  |ang - cos(angle(d, u))| <= DELTA_LIT = 10 * 2^-24  (derivation: DESIGN.md section 4, "rounding band":
+// 8 u from the operations themselves + 1 u from d = fl(h - c), rounded up), as long as no intermediate overflows -- which
+// the two range gates below guarantee.  So the reference's decision can differ from the exact predicate only when
+//     |m| <= |d| |u| DELTA_LIT / (sin t0 cos t0),   m = tau (d . u) - |d x u|,   tau = tan t0,  cos t0 = thresh
+// and the matrix pipe's own evaluation of m (bf16x3 products, float32 accumulation, float32 staging of the per-pixel
+// constants about the image origin o) is off by at most K_FAST * (|h - o| + |c - o|) |u|  (band_constant()).  With
+//     |d| <= |h - o| + |c - o| <= (R + rho) (1 + r / rho),   R = |h - o|,  r = |c - o|,  any rho > 0
+// the band separates into a per-hypothesis and a per-pixel factor, so both fold into the operands at no cost:
+//     B column scaled by  s_j     = 0.9 / ((R_j + rho) kband)         (rounded DOWN to a bf16, so s * c parts stay exact)
+//     A row    scaled by  sigma_i = (rho / (rho + r_i)) / |u_i|       (any float: the direction is normalised as well)
+// give  |s_j sigma_i m| < 1  for every pair inside the band -- also as the matrix pipe computes it.  The two MFMAs return
+//     a' = s sigma (dt - cr),   b' = s sigma (dt + cr)        (dt - |cr| = min(a, b): the |.| is gone from the epilogue)
+// so that  t = clamp(min(a', b'))  [one v_min_f32 with the clamp modifier] is EXACTLY 1.0f for a vote outside the band and
+// 0.0f for a non-vote outside the band, and  dmin = min(dmin, |a'|, |b'|)  [one v_min3_f32] is < 1 whenever a test of the
+// cell lies inside the band (|min(a', b')| is one of |a'|, |b'|).  Cells with dmin >= 1 hold only tests on which the
+// reference's arithmetic and exact arithmetic agree, and their votes are counted as in the approximate mode (two t's per
+// v_add3_u32); a cell with dmin < 1 is re-evaluated with inlier_literal() from the raw records and its t's are discarded.
+// = 2.5 full-rate VALU operations per test (1.5 in the approximate mode).  Measured alternatives (tools/ubench_exact.hip,
+// profiles/r03_ubench_exact.txt): a float16 ramp (v_fma_mixlo/hi_f16) with byte moments (v_perm_b32 + v_dot4_u32_u8) is
+// 1.75 operations per test on paper but VOP3P instructions issue at half rate on gfx950: 12.3 T tests/s against 18.3 T.
+// Range gates: |h - o| >= 2^61 (or not finite) and |u| >= 2^61 would overflow the reference's squares -- such columns /
+// rows are sent as zeros: a' = b' = 0 flags every cell they touch, which is then decided by the reference's arithmetic
+// itself, whatever that does.  Zero records (padding, |u| < 1e-6) and NaN / Inf directions never vote in the reference;
+// their rows are zero except for the spare 16th K slot, A[15] = -4 against B[15] = 1: a' = b' = -4, no vote, no flag.
+constexpr float BAND_TARGET = 0.9f;             // |s sigma m| inside the band (proof obligation: < 1 with the float roundings of the scales)
+constexpr float BAND_FAR = 0x1p61f;             // beyond this the reference's float32 squares may overflow
+__device__ __forceinline__ float band_rho(int tn) {  // the length scale that splits |d| <= (R + rho)(1 + r / rho)
+    const float r = __builtin_sqrtf(0.3183f * (float)tn);  // radius of a disk of tn pixels
+    return r < 8.f ? 8.f : r;
+}
+__device__ __forceinline__ void b_col_exact(float hxo, float hyo, float rho, float kband, uint4& lo, uint4& hi) {
+    const float R = __builtin_sqrtf(fmaf(hxo, hxo, hyo * hyo)) * 1.000001f;
+    float s = BAND_TARGET / ((R + rho) * kband);
+    s = __uint_as_float(__float_as_uint(s) & 0xFFFF0000u);  // round down to bf16: s * (c0 + c1 + c2) stays exact
+    const uint32_t one = 0x3F80u;
+    if (!(R < BAND_FAR) || !(s > 0.f)) {  // too far, Inf or NaN: a' = b' = 0 for every live pixel -> decided literally
+        lo = make_uint4(0u, 0u, 0u, 0u);
+        hi = make_uint4(0u, 0u, 0u, pk(0u, one));
+        return;
+    }
+    uint32_t x0, x1, x2, y0, y1, y2;
+    split3(hxo * s, x0, x1, x2);
+    split3(hyo * s, y0, y1, y2);
+    const uint32_t sb = __float_as_uint(s) >> 16;
+    lo = make_uint4(pk(x0, x0), pk(x1, x0), pk(x2, x1), pk(y0, y0));
+    hi = make_uint4(pk(y1, y0), pk(y2, y1), pk(sb, sb), pk(sb, one));
+}
+// per-pixel rows of a = dt - cr and b = dt + cr, the direction normalised to |M| = sigma <= rho / (rho + r)
+__device__ __forceinline__ void a_rows_exact(float4 q, float tau, float ox, float oy, float rho, uint4& alo, uint4& ahi,
+                                             uint4& blo, uint4& bhi) {
+    const uint32_t never = 0xC080u;  // bf16 -4 in the spare slot: a' = b' = -4
+    alo = ahi = blo = bhi = make_uint4(0u, 0u, 0u, 0u);
+    const float m = fmaxf(fabsf(q.z), fabsf(q.w));
+    const uint32_t e = (__float_as_uint(m) >> 23) & 0xFFu;
+    const bool finite = fabsf(q.z) <= 3.4028235e38f && fabsf(q.w) <= 3.4028235e38f;  // false for NaN and Inf
+    if (!(m > 0.f) || !finite) {  // zero record (padding, |u| < 1e-6), NaN or Inf direction: the reference never votes
+        ahi.w = bhi.w = pk(0u, never);
+        return;
+    }
+    if (e >= 127u + 61u) return;    // finite but >= 2^61: the reference's nx * nx may overflow -- zero rows: decided literally
+    const float pre = __uint_as_float((254u - e) << 23);       // 2^(127 - e): max(|ux|, |uy|) -> [1, 2)   (e = 0: denormal, 2^127)
+    const float u1x = q.z * pre, u1y = q.w * pre;               // exact
+    const float g = __builtin_amdgcn_rsqf(fmaf(u1y, u1y, u1x * u1x));
+    const float cx = q.x - ox, cy = q.y - oy;                   // exact: integer pixel coordinates
+    const float r = __builtin_sqrtf(fmaf(cy, cy, cx * cx));
+    const float gs = g * (rho / (rho + r)) * 0.9997f;           // |M| = |u1| gs <= rho / (rho + r)   (rsq, sqrt, divide: 1 ulp each)
+    const float Mx = u1x * gs, My = u1y * gs;
+    const float Tx = tau * Mx, Ty = tau * My;
+    const float Ec = fmaf(cx, My, -cy * Mx);                    // cr = hx My - hy Mx - Ec
+    const float Ed = fmaf(cx, Tx, cy * Ty);                     // dt = hx Tx + hy Ty - Ed
+    a_row(Tx - My, Ty + Mx, Ec - Ed, alo, ahi);                 // a = dt - cr
+    a_row(Tx + My, Ty - Mx, -Ec - Ed, blo, bhi);                // b = dt + cr
 }
 
 __device__ __forceinline__ int wave_reduce_add(int v) {
@@ -492,8 +579,7 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
             if (LITERAL) {
                 P.rec[o] = make_float4((float)x, (float)y, ux[kk], uy[kk]);
             } else {
-                const float n1 = __builtin_sqrtf(fmaf(uy[kk], uy[kk], ux[kk] * ux[kk]));
-                const bool dead = n1 <= kF1e6;  // zero direction never votes (:121): stored as a zero record
+                const bool dead = norm1_literal(ux[kk], uy[kk]) <= kF1e6;  // never votes (:119-121): stored as a zero record
                 P.rec[o] = make_float4((float)x, (float)y, dead ? 0.f : ux[kk], dead ? 0.f : uy[kk]);
             }
         }
@@ -577,7 +663,11 @@ __device__ __forceinline__ void plan_image(const VoteParams& P, int bi) {
         P.ctrl[bi * CTRL_STRIDE + C_OX] = pm % P.w;
         P.ctrl[bi * CTRL_STRIDE + C_OY] = pm / P.w;
         if (!nch) P.ctrl[bi * CTRL_STRIDE + C_STATUS] |= PVNET_S_SKIPPED;
-        if (bi == P.b - 1) P.ctrl[P.b * CTRL_STRIDE] = base + n;  // total number of work items
+        if (bi == P.b - 1) {
+            P.ctrl[P.b * CTRL_STRIDE] = base + n;  // total number of work items
+            P.ctrl[P.b * CTRL_STRIDE + 4] = 0;     // exact mode, PVNET_F_BAND_STATS: flagged cells / literal tests
+            P.ctrl[P.b * CTRL_STRIDE + 5] = 0;
+        }
     }
     const int HQ = P.hgroups / P.wg_g, nchg = (nch + P.wg_s - 1) / P.wg_s;
     for (int local = threadIdx.x; local < n; local += 256) {
@@ -638,7 +728,8 @@ __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
             oy = (float)(pm / P.w);
         }
         uint4 lo, hi;
-        b_col(hx - ox, hy - oy, lo, hi);
+        if (P.exact) b_col_exact(hx - ox, hy - oy, band_rho(tn), P.kband, lo, hi);
+        else b_col(hx - ox, hy - oy, lo, hi);
         uint4* o = P.hypb + (((size_t)bi * P.vn + k) * P.hn_pad + h) * 2;
         o[0] = lo;
         o[1] = hi;
@@ -917,6 +1008,206 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// K4 (exact mode, the default): the matrix-pipe scoring of score_mfma_kernel with the rounding-band epilogue
+// described above b_col_exact(): counts EQUAL to the reference kernel's, 2.5 VALU operations per test.
+// ------------------------------------------------------------------------------------------------------------
+// Eight tests of the lane's hypothesis: t = clamp(min(a, b)) (the vote, exact outside the band), two of them per
+// v_add3_u32 into the wrapped counter of vote8(); dm = running minimum of |a|, |b| over the cell.
+__device__ __forceinline__ void vote8ab(unsigned& acc, float& dm, float a0, float b0, float a1, float b1, float a2, float b2,
+                                        float a3, float b3, float a4, float b4, float a5, float b5, float a6, float b6,
+                                        float a7, float b7) {
+    float t0, t1, t2;
+    asm volatile(
+        "v_min_f32_e64 %2, %5, %6 clamp\n"        // M0
+        "v_min_f32_e64 %3, %7, %8 clamp\n"        // M1
+        "v_min3_f32 %1, %1, |%5|, |%6|\n"         // D0
+        "v_min_f32_e64 %4, %9, %10 clamp\n"       // M2
+        "v_min3_f32 %1, %1, |%7|, |%8|\n"         // D1
+        "v_add3_u32 %0, %2, %3, %0\n"             // A01
+        "v_min_f32_e64 %2, %11, %12 clamp\n"      // M3
+        "v_min3_f32 %1, %1, |%9|, |%10|\n"        // D2
+        "v_min_f32_e64 %3, %13, %14 clamp\n"      // M4
+        "v_min3_f32 %1, %1, |%11|, |%12|\n"       // D3
+        "v_add3_u32 %0, %4, %2, %0\n"             // A23
+        "v_min_f32_e64 %4, %15, %16 clamp\n"      // M5
+        "v_min3_f32 %1, %1, |%13|, |%14|\n"       // D4
+        "v_min_f32_e64 %2, %17, %18 clamp\n"      // M6
+        "v_min3_f32 %1, %1, |%15|, |%16|\n"       // D5
+        "v_add3_u32 %0, %3, %4, %0\n"             // A45
+        "v_min_f32_e64 %3, %19, %20 clamp\n"      // M7
+        "v_min3_f32 %1, %1, |%17|, |%18|\n"       // D6
+        "v_min3_f32 %1, %1, |%19|, |%20|\n"       // D7
+        "v_add3_u32 %0, %2, %3, %0\n"             // A67
+        : "+v"(acc), "+v"(dm), "=&v"(t0), "=&v"(t1), "=&v"(t2)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5),
+          "v"(a6), "v"(b6), "v"(a7), "v"(b7));
+}
+constexpr float BAND_CLEAN = 1.0f;     // a cell whose minimum |a'|, |b'| reaches this holds no test inside the band
+
+// FOLD1 = false: one cell per (lane, hypothesis tile) and work item -- the minimum runs over all the item's pixel tiles
+//                (cheapest epilogue; right when flagged cells are rare: thresh <= ~0.995 on unit fields);
+// FOLD1 = true:  one cell per (lane, hypothesis tile, PIXEL tile) -- the test is made after every step, so a flagged cell
+//                costs 16 literal tests instead of 16 * tiles (right when the threshold sits inside the field's noise).
+template <int MH, bool FOLD1, bool TIMED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void score_exact_kernel(VoteParams P) {
+    if (MH == 8) PVNET_SPARE_VGPRS(167); else if (MH == 4) PVNET_SPARE_VGPRS(143); else PVNET_SPARE_VGPRS(111);
+    unsigned long long* __restrict__ stamps = reinterpret_cast<unsigned long long*>(P.pix);
+    if (TIMED && threadIdx.x == 0) stamps[2 * blockIdx.x] = (unsigned long long)wall_clock64();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int npx = P.wg_s * P.chunk, ntiles = npx >> 5;
+    uint4* s_t = reinterpret_cast<uint4*>(smem);                        // A tiles: ntiles x 2 KB  (A_a rows | A_b rows)
+    float4* s_raw = reinterpret_cast<float4*>(s_t + ntiles * TILE_U4);  // raw records of the pixel group
+    unsigned* s_cells = reinterpret_cast<unsigned*>(s_raw + npx);       // flagged cells of this item (4 * MH * 64 slots)
+    __shared__ int s_ncell;
+    const int32_t* __restrict__ ctrl = P.ctrl;
+    const int total = ctrl[P.b * CTRL_STRIDE];
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint4* lbase = s_t + col * 2 + half;
+
+    const ItemRange ir = my_items(P, total);
+    for (int item = ir.first; item < ir.end; item += ir.step) {
+        const int4 desc = P.items[item];
+        const int bi = desc.x, k = desc.y, cg = desc.z, hq = desc.w;
+        const int tn = ctrl[bi * CTRL_STRIDE + C_TN];
+        const float ox = (float)ctrl[bi * CTRL_STRIDE + C_OX], oy = (float)ctrl[bi * CTRL_STRIDE + C_OY];
+        const float rho = band_rho(tn);
+        const size_t bk = (size_t)bi * P.vn + k;
+        const int tpad = (tn + PAD - 1) / PAD * PAD;
+        const int hslice = hq * 4 * MH * 32;            // first hypothesis of this work item
+        const int h0 = hslice + wave * MH * 32;         // this wave's first hypothesis
+
+        bf16x8 B[MH];
+#pragma unroll
+        for (int t = 0; t < MH; ++t) {
+            const uint4 raw = P.hypb[(bk * P.hn_pad + h0 + t * 32 + col) * 2 + half];
+            B[t] = __builtin_bit_cast(bf16x8, raw);
+        }
+        __syncthreads();  // the previous item's tiles, raw records and cell list have been consumed
+        if (threadIdx.x == 0) s_ncell = 0;
+        for (int i = threadIdx.x; i < npx; i += 256) {
+            const int p = cg * npx + i;
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < tpad) q = P.rec[bk * P.cap + p];
+            s_raw[i] = q;
+            uint4* t = s_t + (i >> 5) * TILE_U4 + (i & 31) * 2;
+            a_rows_exact(q, P.tau, ox, oy, rho, t[0], t[1], t[64], t[65]);
+        }
+        __syncthreads();
+
+        unsigned cnt[MH];   // wrapped vote counters of the clean cells (vote8)
+        float dmn[MH];      // FOLD1: bit mask of flagged pixel tiles (as an integer); else: min |a'|, |b'| of the cell so far
+#pragma unroll
+        for (int t = 0; t < MH; ++t) {
+            cnt[t] = 0u;
+            dmn[t] = FOLD1 ? 0.f : 3.0e38f;
+        }
+        bf16x8 Aa = __builtin_bit_cast(bf16x8, lbase[0]), Ab = __builtin_bit_cast(bf16x8, lbase[64]);
+        f32x16 va = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aa, B[0], zero, 0, 0, 0);
+        f32x16 vb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ab, B[0], zero, 0, 0, 0);
+        const int left = (tpad - cg * npx + 31) >> 5;
+        const int nti = left < ntiles ? left : ntiles;
+        for (int tile = 0; tile < nti; ++tile) {
+            const int nt = tile + 1 < nti ? tile + 1 : tile;
+            const bf16x8 Na = __builtin_bit_cast(bf16x8, lbase[nt * TILE_U4]);
+            const bf16x8 Nb = __builtin_bit_cast(bf16x8, lbase[nt * TILE_U4 + 64]);
+#pragma unroll
+            for (int t = 0; t < MH; ++t) {
+                unsigned acc = FOLD1 ? 0u : cnt[t];
+                float d = FOLD1 ? 3.0e38f : dmn[t];
+                const f32x16 va2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Aa : Na, B[(t + 1) % MH], zero, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                vote8ab(acc, d, va[0], vb[0], va[1], vb[1], va[2], vb[2], va[3], vb[3], va[4], vb[4], va[5], vb[5],
+                        va[6], vb[6], va[7], vb[7]);
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x16 vb2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Ab : Nb, B[(t + 1) % MH], zero, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                vote8ab(acc, d, va[8], vb[8], va[9], vb[9], va[10], vb[10], va[11], vb[11], va[12], vb[12], va[13],
+                        vb[13], va[14], vb[14], va[15], vb[15]);
+                if (FOLD1) {
+                    const bool bad = !(d >= BAND_CLEAN);
+                    cnt[t] += bad ? 0u : acc;
+                    dmn[t] = __uint_as_float(__float_as_uint(dmn[t]) | ((bad ? 1u : 0u) << tile));
+                } else {
+                    cnt[t] = acc;
+                    dmn[t] = d;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                va = va2;
+                vb = vb2;
+            }
+            Aa = Na;
+            Ab = Nb;
+        }
+        // ---- clean cells: their counts; flagged cells: into the item's list
+        const unsigned all_tiles = (1u << nti) - 1u;  // nti <= 16
+        int colx = col;  // opaque copy: keeps the eight per-tile addresses below from being hoisted above the scoring loop,
+        asm volatile("" : "+v"(colx));  // where they would cost 20 VGPRs at the point of highest pressure
+        int32_t* const pcnt = P.counts + bk * P.hn_pad + h0;
+#pragma unroll
+        for (int t = 0; t < MH; ++t) {
+            unsigned mask;
+            int votes;
+            if (FOLD1) {
+                votes = votes_of(cnt[t]);   // <= 16 * 16 clean votes, wrapped mod 512
+                mask = __float_as_uint(dmn[t]);
+            } else {
+                const bool bad = !(dmn[t] >= BAND_CLEAN);
+                votes = bad ? 0 : votes_of(cnt[t]);
+                mask = bad ? all_tiles : 0u;
+            }
+            const int c = votes + __shfl_xor(votes, 32, 64);  // the half-waves hold different rows of the column
+            if (half == 0 && c > 0) atomicAdd(pcnt + t * 32 + colx, c);
+            if (h0 + t * 32 + colx >= P.hn) mask = 0u;  // padding columns of the last slice: nobody reads their counts
+            const unsigned long long bal = __ballot(mask != 0u);
+            if (bal) {  // wave-uniform
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_ncell, __popcll(bal));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                if (mask != 0u) s_cells[slot] = (unsigned)(wave * MH * 32 + t * 32 + colx) | ((unsigned)half << 10) | (mask << 11);
+            }
+        }
+        __syncthreads();
+        // ---- flagged cells, decided by the reference's arithmetic: 16 lanes per cell, one pixel row each
+        const int ncell = s_ncell;
+        if (ncell > 0) {
+            const int grp = threadIdx.x >> 4, q = threadIdx.x & 15;
+            int ntests = 0;
+            for (int e = grp; e < ncell; e += 16) {
+                const unsigned cell = s_cells[e];
+                const int hl = (int)(cell & 1023u), hf = (int)((cell >> 10) & 1u);
+                unsigned m = cell >> 11;
+                const float2 hv = P.hyp[bk * P.hn_pad + hslice + hl];
+                const int row = (q >> 2) * 8 + hf * 4 + (q & 3);  // the 16 rows a lane of that half-wave holds
+                int votes = 0;
+                while (m) {
+                    const int tile = __ffs((int)m) - 1;
+                    m &= m - 1u;
+                    const float4 r = s_raw[tile * 32 + row];
+                    votes += inlier_literal(r.x, r.y, r.z, r.w, hv.x, hv.y, P.thresh) ? 1 : 0;
+                    ++ntests;
+                }
+                votes += __shfl_xor(votes, 8, 64);
+                votes += __shfl_xor(votes, 4, 64);
+                votes += __shfl_xor(votes, 2, 64);
+                votes += __shfl_xor(votes, 1, 64);
+                if (q == 0 && votes > 0) atomicAdd(P.counts + bk * P.hn_pad + hslice + hl, votes);
+            }
+            if (P.flags & PVNET_F_BAND_STATS) {  // development aid: how much was re-evaluated (tools/band_stats.py)
+                if (threadIdx.x == 0) atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 4, ncell);
+                if (q == 0 && ntests > 0) atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 5, ntests);
+            }
+        }
+    }
+    if (TIMED) {
+        __syncthreads();
+        if (threadIdx.x == 0) stamps[2 * blockIdx.x + 1] = (unsigned long long)wall_clock64();
+    }
+}
+
 // profiling helper of pvnet_vote_v3_stage_repeat: acc[0] += (max end - min start) over the n workgroup slots
 __global__ __launch_bounds__(256) void ts_collect_kernel(const unsigned long long* __restrict__ stamps, int n,
                                                          unsigned long long* __restrict__ acc, int clear) {
@@ -1045,7 +1336,7 @@ __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
         const float4 q = P.rec[bk * P.cap + t];
         const float2 u = rec_dir(q);
         bool in;
-        if (LITERAL) {
+        if (LITERAL || P.exact) {  // (uniform) exact mode: the winner's inliers as the reference's own test finds them (:582-584)
             in = inlier_literal(q.x, q.y, u.x, u.y, wx, wy, P.thresh);
         } else {
             float4 ra;
@@ -1359,6 +1650,32 @@ inline void op_voting_grid(int tn, int vn, int hn, int* hslice, int* slices) {
     *slices = (hn + *hslice - 1) / *hslice;
 }
 
+// Host side of the exact mode's rounding band (device side: b_col_exact / a_rows_exact): half-width of the band as a
+// fraction of |d| |u|, i.e. a test whose exact margin  m = tau (d . u) - |d x u|  satisfies |m| > kband |d| |u| is decided the
+// same way by exact arithmetic, by the reference's float32 kernel and by the matrix pipe.
+//   K_LIT  = DELTA_LIT (1 + tau^2) / tau = DELTA_LIT / (sin t0 cos t0),  DELTA_LIT = 10 u  (u = 2^-24): the reference's
+//            |ang - cos| <= 8 u (dot 2 u, the two norms 2 u each, their product and the quotient 1 u each, times cos <= 1)
+//            + 1 u for d = fl(h - c), rounded up; d(m / |d||u|) / d(cos) = tau + 1 / tau at the threshold;
+//   K_FAST = u (1 + tau) (1.43 C_M + 8): the matrix pipe sums 16 products with |error| <= C_M u sum |terms| (measured
+//            on the MI355X: 4.87, tools/ubench_exact.hip -- taken as 10), sum |terms| <= sqrt(2) (1 + 2^-7) (R + r) |M| per dot
+//            product; the eight further u cover the roundings of M = u g sigma, T = tau M, T +- N, the two constants
+//            Ec, Ed (2 u r |M| each), h - o, (h - o) s, tau itself and the three dropped part pairs of the bf16x3 split
+//            (0.52 u).
+// Doubled for the final safety margin -- the band is ~1e-5 of the tests at thresh 0.99, so its width costs nothing.
+float band_constant(float thresh) {
+    const double u = ldexp(1.0, -24), t = (double)thresh;
+    const double tau = sqrt(1.0 - t * t) / t;
+    const double k_lit = 10.0 * u * (1.0 + tau * tau) / tau * 1.001;
+    const double k_fast = u * (1.0 + tau) * (1.43 * 10.0 + 8.0);
+    return (float)(2.0 * (k_lit + k_fast));
+}
+// cell size of the exact mode: per pixel tile when the band is wide (thresh -> 1: 1 / sin t0 grows and the threshold angle
+// moves into the noise of a real vector field, so many cells hold a test inside the band), per work item otherwise
+int band_fold1(int forced, float thresh) {
+    if (forced == 0 || forced == 1) return forced;
+    return thresh > 0.995f ? 1 : 0;
+}
+
 int env_int(const char* name, int dflt) {
     const char* s = getenv(name);
     return (s && *s) ? atoi(s) : dflt;
@@ -1379,6 +1696,8 @@ struct Tuning {
                         //                         for other streams' small stages; 0 = no padding
     int score_atomic;   // PVNET_SCORE_ATOMIC      1 (default): K4 adds its counts into `counts` with integer atomics;
                         //                         0: per-chunk uint16 count rows (`partial`) summed by K5
+    int exact_fold;     // PVNET_EXACT_FOLD        exact mode: -1 (default) = by threshold, 0 = one cell per work item and
+                        //                         hypothesis, 1 = one cell per pixel tile (band_fold1())
     int dev_stages;     // PVNET_DEV_STAGES        development aid: bit mask of the stages to launch
     int cus;            // compute units of the device (all GPUs of a node are the same part)
 };
@@ -1391,6 +1710,7 @@ void load_tuning(Tuning& t) {
     t.score_xcd = env_int("PVNET_SCORE_XCD", 1);
     t.score_atomic = env_int("PVNET_SCORE_ATOMIC", 1);
     t.score_lds_kb = env_int("PVNET_SCORE_LDS_KB", 0);
+    t.exact_fold = env_int("PVNET_EXACT_FOLD", -1);
     t.dev_stages = env_int("PVNET_DEV_STAGES", 0x3F);
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -1493,7 +1813,32 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
         if (wgs > max_items) wgs = max_items;
         if (wgs < 1) wgs = 1;
         if (score_grid) *score_grid = (int)wgs;
-        if (!literal && P.mode) {
+        if (P.exact) {
+            const int mh = P.wg_g * P.hpl / 2;
+            const int npx = P.wg_s * P.chunk;
+            const size_t lds = (size_t)(npx / 32) * TILE_U4 * sizeof(uint4) + (size_t)npx * sizeof(float4) +
+                               (size_t)4 * mh * 64 * sizeof(unsigned);
+            const dim3 g((unsigned)wgs), t(256);
+            const bool fold1 = P.fold1 != 0;
+#define PV_EXACT(MH_)                                                                                               \
+    do {                                                                                                            \
+        if (timed_score) {                                                                                          \
+            if (fold1) hipLaunchKernelGGL((score_exact_kernel<MH_, true, true>), g, t, lds, s, P);                  \
+            else hipLaunchKernelGGL((score_exact_kernel<MH_, false, true>), g, t, lds, s, P);                       \
+        } else {                                                                                                    \
+            if (fold1) hipLaunchKernelGGL((score_exact_kernel<MH_, true, false>), g, t, lds, s, P);                 \
+            else hipLaunchKernelGGL((score_exact_kernel<MH_, false, false>), g, t, lds, s, P);                      \
+        }                                                                                                           \
+    } while (0)
+            switch (mh) {
+                case 1: PV_EXACT(1); break;
+                case 2: PV_EXACT(2); break;
+                case 4: PV_EXACT(4); break;
+                case 8: PV_EXACT(8); break;
+                default: return PVNET_E_UNSUPPORTED;
+            }
+#undef PV_EXACT
+        } else if (!literal && P.mode) {
             const int mh = P.wg_g * P.hpl / 2;  // hypotheses per item = wg_g * 64 * hpl = 4 waves * mh * 32
             size_t lds = (size_t)(P.wg_s * P.chunk / 32) * TILE_U4 * sizeof(uint4);
             if (T.score_lds_kb > 0 && T.score_lds_kb <= 64 && lds < (size_t)T.score_lds_kb * 1024) lds = (size_t)T.score_lds_kb * 1024;
@@ -1563,6 +1908,12 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     P.atomic_counts = tuning().score_atomic;
     P.thresh = thresh;
     P.tau = (thresh > 0.f && thresh < 1.f) ? (float)(sqrt(1.0 - (double)thresh * thresh) / (double)thresh) : 0.f;
+    // exact mode (the default): matrix-pipe scoring + literal re-evaluation inside the rounding band; needs the B-operand
+    // buffer (PVNET_SCORE_MODE=1) and counts by atomics (the re-evaluated cells add theirs the same way)
+    P.exact = (!(flags & (PVNET_F_LITERAL | PVNET_F_APPROX)) && L.reserved_) ? 1 : 0;
+    P.kband = P.exact ? band_constant(thresh) : 0.f;
+    P.fold1 = P.exact ? band_fold1(tuning().exact_fold, thresh) : 0;
+    if (P.exact) P.atomic_counts = 1;
     P.min_num = min_num; P.max_num = max_num; P.seed = seed; P.image_base = image_base; P.idxs = idxs; P.flags = flags;
     P.ctrl = reinterpret_cast<int32_t*>(base + L.off_ctrl);
     P.items = reinterpret_cast<int4*>(base + L.off_items);

@@ -26,6 +26,8 @@ LIB_PATH = os.path.join(_HERE, "libpvnet_vote.so")
 F_LITERAL = 1
 F_NO_REFINE = 2
 F_VERTEX_F16, F_VERTEX_BF16, F_LOGITS_F16, F_LOGITS_BF16 = 4, 8, 16, 32
+F_APPROX = 64        # the round-1/2 "fast" mode: matrix-pipe scoring without the rounding-band re-evaluation
+F_BAND_STATS = 128   # development aid: count the re-evaluated cells / literal tests (exact mode)
 S_SKIPPED, S_SINGULAR, S_NO_INLIER, S_OVERFLOW = 1, 2, 4, 8
 NUM_STAGES = 6
 STAGE_NAMES = ("mask_bits", "subsample", "compact", "hypotheses", "score", "select_refine")
@@ -92,7 +94,7 @@ def load_library() -> C.CDLL:
     lib.pvnet_vote_distribution.argtypes = [f32p, f32p] + ws_tail
     lib.pvnet_vote_tuning_reload.restype = None
     lib.pvnet_vote_tuning_reload.argtypes = []
-    if lib.pvnet_vote_abi_version() != 5:
+    if lib.pvnet_vote_abi_version() != 6:
         raise RuntimeError("pvnet_amd: libpvnet_vote.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib
@@ -184,6 +186,16 @@ def effective_literal(literal: bool, inlier_thresh: float) -> bool:
     return bool(literal) or not (0.0 < t < 1.0)
 
 
+def mode_flags(literal: bool, approx: bool, inlier_thresh: float) -> int:
+    """scoring-mode bits of a call.  Default (neither): EXACT mode -- matrix-pipe scoring whose inlier counts and winners
+    equal the reference kernels' (pairs inside the float32 rounding band of kernel.cu:107-125 are re-evaluated in the
+    reference's operation order); ``literal``: the reference's order for every pair on the VALU (~10x slower);
+    ``approx``: matrix-pipe scoring without the re-evaluation (counts within a few votes of the reference's)."""
+    if effective_literal(literal, inlier_thresh):
+        return F_LITERAL
+    return F_APPROX if approx else 0
+
+
 def _workspace(workspace, L: Layout, dev) -> torch.Tensor:
     if workspace is None:
         return torch.empty(L.total_bytes, dtype=torch.uint8, device=dev)
@@ -206,8 +218,9 @@ def _strip_return_kw(kw: dict) -> dict:
 
 def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99, max_iter=20,
                            min_num=5, max_num=30000, *, idxs: Optional[torch.Tensor] = None,
-                           seed: Optional[int] = None, image_offset: int = 0, literal: bool = False, refine: bool = True,
-                           return_status: bool = False, return_debug: bool = False, stage_times: bool = False,
+                           seed: Optional[int] = None, image_offset: int = 0, literal: bool = False, approx: bool = False,
+                           refine: bool = True, return_status: bool = False, return_debug: bool = False,
+                           stage_times: bool = False, band_stats: bool = False,
                            workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
     """Drop-in for the reference's ``ransac_voting_layer_v3`` (ransac_voting_gpu.py:514-598).
 
@@ -226,7 +239,11 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
       seed    RNG seed (default: drawn from torch's CPU generator, so ``torch.manual_seed`` makes runs repeatable)
       image_offset  global index of this call's first image (RNG stream = image_offset + i): lets a batch sharded
               over GPUs reproduce the unsharded draw exactly
-      literal score with the reference's float32 operation order (bit-exact with the float32 oracle, slower)
+      (default scoring mode: EXACT -- matrix pipe, inlier counts and winners equal to the reference kernels', see mode_flags)
+      literal score with the reference's float32 operation order for every pair (bit-exact as well, ~10x slower)
+      approx  matrix-pipe scoring without the rounding-band re-evaluation (~10 % faster; counts may differ from the
+              reference's float32 kernels by a few votes where the reference's own rounding decides a pair)
+      band_stats  (exact mode, with return_debug) also count the re-evaluated cells / literal tests: debug["band_stats"]
       refine  False skips the least-squares refinement (:579-595) and returns the winning hypotheses
       return_status / return_debug / stage_times: also return the per-(image,kp) status bits / typed views of
               the workspace / per-stage GPU milliseconds (synchronises; for bench.py)
@@ -242,7 +259,8 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
     if seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     literal = effective_literal(literal, inlier_thresh)
-    flags = (F_LITERAL if literal else 0) | (0 if refine else F_NO_REFINE) | _FIELD_FLAGS[vertex.dtype]
+    flags = mode_flags(literal, approx, inlier_thresh) | (0 if refine else F_NO_REFINE) | _FIELD_FLAGS[vertex.dtype] | \
+        (F_BAND_STATS if band_stats else 0)
     L = vote_layout(b, h, w, vn, hn, max_num)
     with torch.cuda.device(dev):
         ws = _workspace(workspace, L, dev)
@@ -272,6 +290,9 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
     if return_debug:
         d = _debug_views(ws, L)
         d["literal"] = bool(literal)
+        d["mode"] = "literal" if literal else ("approx" if approx else "exact")
+        if band_stats:  # (cells re-evaluated, literal tests made) of this call; synchronises
+            d["band_stats"] = tuple(int(x) for x in d["ctrl"][b, 4:6].tolist())
         d["status"] = status
         d["seed"] = seed
         d["workspace"] = ws
@@ -282,14 +303,14 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
 
 
 def stage_repeat_ms(mask, vertex, round_hyp_num, inlier_thresh=0.999, min_num=5, max_num=30000, *, stage="score",
-                    repeats=200, seed=0, image_offset=0, literal=False, both=False):
+                    repeats=200, seed=0, image_offset=0, literal=False, approx=False, both=False):
     """profiling: average GPU milliseconds of ONE stage (a name of STAGE_NAMES) re-launched ``repeats`` times after one
     complete pass (``pvnet_vote_v3_stage_repeat``); synchronises.  For the fast-mode scoring stage the value is the
     kernel's own duration from device clock stamps; ``both=True`` also returns the back-to-back event average."""
     lib = load_library()
     mask, vertex, b, h, w, vn, hn, max_num, _ = _prepare(mask, vertex, round_hyp_num, max_num, None)
     dev = vertex.device
-    flags = (F_LITERAL if effective_literal(literal, inlier_thresh) else 0) | _FIELD_FLAGS[vertex.dtype]
+    flags = mode_flags(literal, approx, inlier_thresh) | _FIELD_FLAGS[vertex.dtype]
     L = vote_layout(b, h, w, vn, hn, max_num)
     with torch.cuda.device(dev):
         ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=dev)
@@ -318,7 +339,7 @@ class VotePlan:
     returned tensor is overwritten by the next call (clone it to keep it)."""
 
     def __init__(self, mask, vertex, round_hyp_num, inlier_thresh=0.999, min_num=5, max_num=30000, *, literal=False,
-                 refine=True):
+                 approx=False, refine=True):
         self.lib = load_library()
         mask, vertex, b, h, w, vn, hn, max_num, _ = _prepare(mask, vertex, round_hyp_num, max_num, None)
         self.key = (mask.dtype, tuple(mask.shape), tuple(mask.stride()), vertex.dtype, tuple(vertex.shape),
@@ -326,7 +347,7 @@ class VotePlan:
         self.dev = vertex.device
         self.layout = vote_layout(b, h, w, vn, hn, max_num)
         self.literal = effective_literal(literal, inlier_thresh)
-        flags = (F_LITERAL if self.literal else 0) | (0 if refine else F_NO_REFINE) | _FIELD_FLAGS[vertex.dtype]
+        flags = mode_flags(self.literal, approx, inlier_thresh) | (0 if refine else F_NO_REFINE) | _FIELD_FLAGS[vertex.dtype]
         with torch.cuda.device(self.dev):
             self.workspace = torch.empty(self.layout.total_bytes, dtype=torch.uint8, device=self.dev)
             self.out = torch.empty((b, vn, 2), dtype=torch.float32, device=self.dev)
@@ -340,9 +361,10 @@ class VotePlan:
         if (mask.dtype, tuple(mask.shape), tuple(mask.stride()), vertex.dtype, tuple(vertex.shape),
                 tuple(vertex.stride()), vertex.device) != self.key:
             raise RuntimeError("VotePlan: tensors differ in dtype / shape / strides / device from the planned call")
-        rc = self.lib.pvnet_vote_v3(mask.data_ptr(), *self._head, vertex.data_ptr(), *self._mid,
-                                    seed & 0xFFFFFFFFFFFFFFFF, image_offset, *self._tail,
-                                    torch.cuda.current_stream(self.dev).cuda_stream)
+        with torch.cuda.device(self.dev):  # the library launches on the CURRENT device (as ransac_voting_layer_v3 does)
+            rc = self.lib.pvnet_vote_v3(mask.data_ptr(), *self._head, vertex.data_ptr(), *self._mid,
+                                        seed & 0xFFFFFFFFFFFFFFFF, image_offset, *self._tail,
+                                        torch.cuda.current_stream(self.dev).cuda_stream)
         if rc:
             _check(rc, "pvnet_vote_v3")
         return self.out
@@ -356,7 +378,8 @@ def debug_dir(dbg) -> torch.Tensor:
 
 def ransac_voting_layer_v3_from_logits(seg_pred, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99,
                                        max_iter=20, min_num=5, max_num=30000, *, idxs=None, seed=None,
-                                       image_offset=0, literal=False, refine=True):
+                                       image_offset=0, literal=False, approx=False, refine=True, workspace=None,
+                                       out=None):
     """``ransac_voting_layer_v3(torch.argmax(seg_pred, 1), vertex, ...)`` with the arg-max fused into the first
     kernel: the class logits ``seg_pred [b,C,h,w]`` float32 are read in place and the int64 mask the reference
     materialises (tools/demo.py:52) never exists.  Same result as the two-step call."""
@@ -372,12 +395,16 @@ def ransac_voting_layer_v3_from_logits(seg_pred, vertex, round_hyp_num, inlier_t
     dev = vertex.device
     if seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-    flags = (F_LITERAL if effective_literal(literal, inlier_thresh) else 0) | (0 if refine else F_NO_REFINE) | \
+    flags = mode_flags(literal, approx, inlier_thresh) | (0 if refine else F_NO_REFINE) | \
         _FIELD_FLAGS[vertex.dtype] | _LOGITS_FLAGS[seg_pred.dtype]
     L = vote_layout(b, h, w, vn, hn, max_num)
     with torch.cuda.device(dev):
-        ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=dev)
-        out = torch.empty((b, vn, 2), dtype=torch.float32, device=dev)
+        ws = _workspace(workspace, L, dev)  # caller-owned (reused across calls) or a fresh 171 MB at batch 32
+        if out is None:
+            out = torch.empty((b, vn, 2), dtype=torch.float32, device=dev)
+        elif not (out.is_cuda and out.device == dev and out.dtype == torch.float32 and out.is_contiguous() and
+                  tuple(out.shape) == (b, vn, 2)):
+            raise RuntimeError(f"out must be a contiguous float32 CUDA tensor of shape {(b, vn, 2)} on {dev}")
         _check(lib.pvnet_vote_v3_logits(
             C.c_void_p(seg_pred.data_ptr()), _strides(seg_pred, 4), nc, C.c_void_p(vertex.data_ptr()),
             _strides(vertex, 5), b, h, w, vn, hn, C.c_float(inlier_thresh), int(min_num), max_num,

@@ -1,4 +1,4 @@
-"""Build-time check of the matrix-pipe scoring kernels' hand-placed vote epilogue (pvnet_vote.hip: vote8).
+"""Build-time check of the matrix-pipe scoring kernels' hand-placed vote epilogues (pvnet_vote.hip: vote8, vote8ab).
 
 vote8 reads MFMA result VGPRs from inside an inline-asm block.  LLVM inserts the gfx950 "XDL write VGPR -> VALU read"
 wait states only for instructions IT schedules; what an INLINEASM block reads is invisible to its hazard recogniser,
@@ -23,6 +23,9 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PASSES = {"v_mfma_f32_32x32x16_bf16": 8, "v_mfma_f32_32x32x16_f16": 8, "v_mfma_f32_16x16x32_bf16": 4,
           "v_mfma_f32_32x32x2_f32": 16, "v_mfma_f32_16x16x4_f32": 8}
+
+
+KERNELS = ("score_mfma_kernel", "score_exact_kernel")  # every kernel whose epilogue reads MFMA results from inline asm
 
 
 def required(op):
@@ -127,12 +130,12 @@ def main(argv):
     funcs = parse_functions(text)
     total, bad = 0, []
     for name, items in funcs.items():
-        if "score_mfma_kernel" not in name:
+        if not any(k in name for k in KERNELS):
             continue
         n, p = check_function(name, items)
         total += n
         bad += p
-    print(f"checked {total} v_mfma instructions in {sum('score_mfma_kernel' in f for f in funcs)} scoring kernels")
+    print(f"checked {total} v_mfma instructions in {sum(any(k in f for k in KERNELS) for f in funcs)} scoring kernels")
     for name, i, op, d, j, mn, oo, used, need in bad:
         print(f"HAZARD {name}: {op} {d} (item {i}) -> {mn} {oo} (item {j}) after {used} wait states, {need} needed")
     return 1 if bad or total == 0 else 0

@@ -1,0 +1,328 @@
+// Micro-benchmark + instruction-semantics check (development aid, not product) for the EXACT scoring epilogue:
+//   t   = clamp(dt - |cr|)            one v_fma_mixlo/hi_f16 per test: a saturating ramp, stored as f16 (two tests per VGPR)
+//   x   = top bytes of four t's       one v_perm_b32 per four tests: 0x00 (no vote), 0x3C (vote), anything else = "near the threshold"
+//   S1 += sum x,  S2 += sum x^2       two v_dot4_u32_u8 per four tests
+// All x in {0, 0x3C}  <=>  0x3C * S1 == S2  (x (0x3C - x) > 0 for every other byte; no wrap: S2 <= 256 * 0x3C^2).
+// = 1.75 VALU operations per test against the 1.5 of the plain clamp + add3 epilogue (vote8i, copied here as the baseline).
+// Also measures the matrix pipe's accumulation error against exact arithmetic (the constant the rounding band needs).
+// hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form tools/ubench_exact.hip -o tools/ubench_exact.bin
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short u16;
+
+__host__ __device__ inline u16 bf16_rn(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (u16)(u >> 16);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (u16)(u >> 16);
+}
+__host__ __device__ inline float bf16_f(u16 h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// 1. instruction semantics: every lane gets 8 (d, c) pairs, returns w0..w3, x0, x1, S1, S2
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void vote8x(unsigned& s1, unsigned& s2, unsigned sel, unsigned ones, float d0, float c0, float d1,
+                                       float c1, float d2, float c2, float d3, float c3, float d4, float c4, float d5,
+                                       float c5, float d6, float c6, float d7, float c7) {
+    unsigned w0, w1, w2, w3;
+    asm volatile(
+        "v_fma_mixlo_f16 %2, %8, 1.0, -|%9| clamp\n"
+        "v_fma_mixlo_f16 %3, %12, 1.0, -|%13| clamp\n"
+        "v_fma_mixlo_f16 %4, %16, 1.0, -|%17| clamp\n"
+        "v_fma_mixlo_f16 %5, %20, 1.0, -|%21| clamp\n"
+        "v_fma_mixhi_f16 %2, %10, 1.0, -|%11| clamp\n"
+        "v_fma_mixhi_f16 %3, %14, 1.0, -|%15| clamp\n"
+        "v_fma_mixhi_f16 %4, %18, 1.0, -|%19| clamp\n"
+        "v_fma_mixhi_f16 %5, %22, 1.0, -|%23| clamp\n"
+        "v_perm_b32 %2, %3, %2, %6\n"
+        "v_perm_b32 %4, %5, %4, %6\n"
+        "v_dot4_u32_u8 %0, %2, %7, %0\n"
+        "v_dot4_u32_u8 %1, %2, %2, %1\n"
+        "v_dot4_u32_u8 %0, %4, %7, %0\n"
+        "v_dot4_u32_u8 %1, %4, %4, %1\n"
+        : "+v"(s1), "+v"(s2), "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
+        : "v"(sel), "v"(ones), "v"(d0), "v"(c0), "v"(d1), "v"(c1), "v"(d2), "v"(c2), "v"(d3), "v"(c3), "v"(d4), "v"(c4),
+          "v"(d5), "v"(c5), "v"(d6), "v"(c6), "v"(d7), "v"(c7));
+}
+// the same with 16-bit moments (no byte packing): 2.0 operations per test
+__device__ __forceinline__ void vote8y(unsigned& s1, unsigned& s2, unsigned ones, float d0, float c0, float d1, float c1,
+                                       float d2, float c2, float d3, float c3, float d4, float c4, float d5, float c5,
+                                       float d6, float c6, float d7, float c7) {
+    unsigned w0, w1, w2, w3;
+    asm volatile(
+        "v_fma_mixlo_f16 %2, %7, 1.0, -|%8| clamp\n"
+        "v_fma_mixlo_f16 %3, %11, 1.0, -|%12| clamp\n"
+        "v_fma_mixlo_f16 %4, %15, 1.0, -|%16| clamp\n"
+        "v_fma_mixlo_f16 %5, %19, 1.0, -|%20| clamp\n"
+        "v_fma_mixhi_f16 %2, %9, 1.0, -|%10| clamp\n"
+        "v_fma_mixhi_f16 %3, %13, 1.0, -|%14| clamp\n"
+        "v_fma_mixhi_f16 %4, %17, 1.0, -|%18| clamp\n"
+        "v_fma_mixhi_f16 %5, %21, 1.0, -|%22| clamp\n"
+        "v_dot2_u32_u16 %0, %2, %6, %0\n"
+        "v_dot2_u32_u16 %1, %2, %2, %1\n"
+        "v_dot2_u32_u16 %0, %3, %6, %0\n"
+        "v_dot2_u32_u16 %1, %3, %3, %1\n"
+        "v_dot2_u32_u16 %0, %4, %6, %0\n"
+        "v_dot2_u32_u16 %1, %4, %4, %1\n"
+        "v_dot2_u32_u16 %0, %5, %6, %0\n"
+        "v_dot2_u32_u16 %1, %5, %5, %1\n"
+        : "+v"(s1), "+v"(s2), "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
+        : "v"(ones), "v"(d0), "v"(c0), "v"(d1), "v"(c1), "v"(d2), "v"(c2), "v"(d3), "v"(c3), "v"(d4), "v"(c4), "v"(d5),
+          "v"(c5), "v"(d6), "v"(c6), "v"(d7), "v"(c7));
+}
+__device__ __forceinline__ void vote8i(unsigned& acc, float d0, float c0, float d1, float c1, float d2, float c2, float d3,
+                                       float c3, float d4, float c4, float d5, float c5, float d6, float c6, float d7,
+                                       float c7) {
+    float t0, t1, t2, t3;
+    asm volatile(
+        "v_sub_f32_e64 %1, %5, |%6| clamp\n"
+        "v_sub_f32_e64 %2, %7, |%8| clamp\n"
+        "v_sub_f32_e64 %3, %9, |%10| clamp\n"
+        "v_sub_f32_e64 %4, %11, |%12| clamp\n"
+        "v_add3_u32 %0, %1, %2, %0\n"
+        "v_sub_f32_e64 %1, %13, |%14| clamp\n"
+        "v_sub_f32_e64 %2, %15, |%16| clamp\n"
+        "v_add3_u32 %0, %3, %4, %0\n"
+        "v_sub_f32_e64 %3, %17, |%18| clamp\n"
+        "v_sub_f32_e64 %4, %19, |%20| clamp\n"
+        "v_add3_u32 %0, %1, %2, %0\n"
+        "v_add3_u32 %0, %3, %4, %0\n"
+        : "+v"(acc), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(d0), "v"(c0), "v"(d1), "v"(c1), "v"(d2), "v"(c2), "v"(d3), "v"(c3), "v"(d4), "v"(c4), "v"(d5), "v"(c5),
+          "v"(d6), "v"(c6), "v"(d7), "v"(c7));
+}
+
+__global__ void k_semantics(const float* __restrict__ d, const float* __restrict__ c, unsigned* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float dv[8], cv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { dv[q] = d[i * 8 + q]; cv[q] = c[i * 8 + q]; }
+    unsigned s1 = 0, s2 = 0, t1 = 0, t2 = 0;
+    vote8x(s1, s2, 0x07050301u, 0x01010101u, dv[0], cv[0], dv[1], cv[1], dv[2], cv[2], dv[3], cv[3], dv[4], cv[4], dv[5], cv[5],
+           dv[6], cv[6], dv[7], cv[7]);
+    vote8y(t1, t2, 0x00010001u, dv[0], cv[0], dv[1], cv[1], dv[2], cv[2], dv[3], cv[3], dv[4], cv[4], dv[5], cv[5], dv[6], cv[6],
+           dv[7], cv[7]);
+    out[i * 4 + 0] = s1;
+    out[i * 4 + 1] = s2;
+    out[i * 4 + 2] = t1;
+    out[i * 4 + 3] = t2;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 2. matrix-pipe accumulation error: D = A (32 x 16) * B (16 x 32), bf16 operands, against float64
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_mfma_err(const u16* __restrict__ A, const u16* __restrict__ B, float* __restrict__ D) {
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+    const size_t blk = blockIdx.x;
+    bf16x8 a, b;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a[k] = __builtin_bit_cast(__bf16, A[blk * 512 + col * 16 + half * 8 + k]);  // row = col (A rows indexed by lane & 31)
+        b[k] = __builtin_bit_cast(__bf16, B[blk * 512 + col * 16 + half * 8 + k]);  // column = col
+    }
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const f32x16 r = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, zero, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int row = (q >> 2) * 8 + half * 4 + (q & 3);
+        D[blk * 1024 + row * 32 + col] = r[q];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3. throughput beside the MFMAs (the pipeline of the product kernel: PIPE 4 of tools/ubench_mfma.hip)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TILE_BYTES = 2 * 32 * 16 * 2;
+template <int MH, int EPI>  // EPI 0: clamp + add3 (1.5 op)   1: mix + perm + dot4 moments (1.75)   2: mix + dot2 moments (2.0)
+__global__ __launch_bounds__(256) void k_pipe(const u16* __restrict__ Bsrc, const u16* __restrict__ Asrc,
+                                              unsigned* __restrict__ counts, int ntiles, int reps) {
+    extern __shared__ __attribute__((aligned(16))) u16 lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    for (int i = threadIdx.x; i < ntiles * TILE_BYTES / 2; i += 256) lds[i] = Asrc[i];
+    bf16x8 B[MH];
+    unsigned s1[MH], s2[MH];
+#pragma unroll
+    for (int t = 0; t < MH; ++t) {
+        const int j = (wave * MH + t) * 32 + (lane & 31);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) B[t][k] = __builtin_bit_cast(__bf16, Bsrc[j * 16 + half * 8 + k]);
+        s1[t] = 0u;
+        s2[t] = 0u;
+    }
+    __syncthreads();
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const char* lbase = reinterpret_cast<const char*>(lds) + (lane & 31) * 32 + half * 16;
+    const unsigned sel = 0x07050301u, ones8 = 0x01010101u, ones16 = 0x00010001u;
+    for (int r = 0; r < reps; ++r) {
+        bf16x8 Acr = *reinterpret_cast<const bf16x8*>(lbase), Ad = *reinterpret_cast<const bf16x8*>(lbase + 1024);
+        f32x16 cr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Acr, B[0], zero, 0, 0, 0);
+        f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ad, B[0], zero, 0, 0, 0);
+        for (int tile = 0; tile < ntiles; ++tile) {
+            const int nt = tile + 1 < ntiles ? tile + 1 : tile;
+            const bf16x8 Ncr = *reinterpret_cast<const bf16x8*>(lbase + nt * TILE_BYTES);
+            const bf16x8 Nd = *reinterpret_cast<const bf16x8*>(lbase + nt * TILE_BYTES + 1024);
+#pragma unroll
+            for (int t = 0; t < MH; ++t) {
+                const f32x16 cr2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Acr : Ncr, B[(t + 1) % MH], zero, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (EPI == 0) vote8i(s1[t], d[0], cr[0], d[1], cr[1], d[2], cr[2], d[3], cr[3], d[4], cr[4], d[5], cr[5], d[6], cr[6], d[7], cr[7]);
+                else if (EPI == 1) vote8x(s1[t], s2[t], sel, ones8, d[0], cr[0], d[1], cr[1], d[2], cr[2], d[3], cr[3], d[4], cr[4], d[5], cr[5], d[6], cr[6], d[7], cr[7]);
+                else vote8y(s1[t], s2[t], ones16, d[0], cr[0], d[1], cr[1], d[2], cr[2], d[3], cr[3], d[4], cr[4], d[5], cr[5], d[6], cr[6], d[7], cr[7]);
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x16 d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Ad : Nd, B[(t + 1) % MH], zero, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (EPI == 0) vote8i(s1[t], d[8], cr[8], d[9], cr[9], d[10], cr[10], d[11], cr[11], d[12], cr[12], d[13], cr[13], d[14], cr[14], d[15], cr[15]);
+                else if (EPI == 1) vote8x(s1[t], s2[t], sel, ones8, d[8], cr[8], d[9], cr[9], d[10], cr[10], d[11], cr[11], d[12], cr[12], d[13], cr[13], d[14], cr[14], d[15], cr[15]);
+                else vote8y(s1[t], s2[t], ones16, d[8], cr[8], d[9], cr[9], d[10], cr[10], d[11], cr[11], d[12], cr[12], d[13], cr[13], d[14], cr[14], d[15], cr[15]);
+                __builtin_amdgcn_sched_barrier(0);
+                cr = cr2;
+                d = d2;
+            }
+            Acr = Ncr;
+            Ad = Nd;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MH; ++t)
+        counts[(((size_t)blockIdx.x * 4 + wave) * MH + t) * 64 + lane] = s1[t] ^ s2[t];
+}
+
+static float h2f(unsigned short h) { _Float16 x = __builtin_bit_cast(_Float16, h); return (float)x; }
+
+int main() {
+    int cus = 256;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+    srand(7);
+    auto rnd = [] { return (float)rand() / RAND_MAX; };
+    // ---- 1. semantics
+    {
+        const int n = 64 * 64;
+        std::vector<float> d(n * 8), c(n * 8);
+        for (int i = 0; i < n * 8; ++i) {
+            const int kind = rand() % 8;
+            float dv, cv;
+            if (kind == 0) { dv = rnd() * 1000.f; cv = dv + 5.f + rnd() * 100.f; cv = rand() & 1 ? cv : -cv; }          // far below: 0
+            else if (kind == 1) { cv = (rnd() - .5f) * 1000.f; dv = fabsf(cv) + 1.f + rnd() * 50.f; }                  // far above: 1
+            else if (kind == 2) { cv = (rnd() - .5f) * 100.f; dv = fabsf(cv) + rnd(); }                                // in the ramp
+            else if (kind == 3) { cv = (rnd() - .5f) * 4.f; dv = fabsf(cv) + 0.5f; }                                   // exactly 0.5 (often)
+            else if (kind == 4) { cv = 0.f; dv = ldexpf(1.f, -(rand() % 30)); }                                         // powers of two
+            else if (kind == 5) { cv = NAN; dv = 1.f; }
+            else if (kind == 6) { cv = 3.f; dv = INFINITY; }
+            else { cv = (rnd() - .5f) * 2.f; dv = fabsf(cv) + 1.f - ldexpf(1.f, -(rand() % 26)); }                      // just below 1
+            d[i] = dv; c[i] = cv;
+        }
+        float *dd, *dc; unsigned* dout;
+        hipMalloc(&dd, n * 32); hipMalloc(&dc, n * 32); hipMalloc(&dout, n * 16);
+        hipMemcpy(dd, d.data(), n * 32, hipMemcpyHostToDevice);
+        hipMemcpy(dc, c.data(), n * 32, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_semantics, dim3(n / 64), dim3(64), 0, 0, dd, dc, dout);
+        std::vector<unsigned> out(n * 4);
+        hipMemcpy(out.data(), dout, n * 16, hipMemcpyDeviceToHost);
+        long bad8 = 0, bad16 = 0, nfrac = 0, nvote = 0, detect_miss = 0;
+        for (int i = 0; i < n; ++i) {
+            unsigned e1 = 0, e2 = 0, f1 = 0, f2 = 0;
+            bool anyfrac = false;
+            for (int q = 0; q < 8; ++q) {
+                float t = d[i * 8 + q] - fabsf(c[i * 8 + q]);
+                t = t != t ? 0.f : (t < 0.f ? 0.f : (t > 1.f ? 1.f : t));
+                const _Float16 hh = (_Float16)t;  // round to nearest even
+                const unsigned short p = __builtin_bit_cast(unsigned short, hh);
+                const unsigned b = p >> 8;
+                e1 += b; e2 += b * b; f1 += p; f2 += (unsigned)p * p;
+                if (b != 0 && b != 0x3C) anyfrac = true;
+                nvote += p == 0x3C00;
+            }
+            nfrac += anyfrac;
+            if (out[i * 4] != e1 || out[i * 4 + 1] != e2) { if (++bad8 <= 5) printf("  lane %d: u8 moments %u %u, expected %u %u\n", i, out[i*4], out[i*4+1], e1, e2); }
+            if (out[i * 4 + 2] != f1 || out[i * 4 + 3] != f2) { if (++bad16 <= 5) printf("  lane %d: u16 moments %u %u, expected %u %u\n", i, out[i*4+2], out[i*4+3], f1, f2); }
+            if (anyfrac && 0x3Cu * out[i * 4] == out[i * 4 + 1]) ++detect_miss;
+        }
+        printf("semantics: %d lanes x 8 tests: u8 moments wrong in %ld lanes, u16 moments wrong in %ld lanes; %ld lanes hold a fractional byte, %ld of them undetected by 0x3C*S1 != S2; %ld votes\n",
+               n, bad8, bad16, nfrac, detect_miss, nvote);
+        (void)h2f;
+    }
+    // ---- 2. MFMA accumulation error
+    {
+        const int nb = 4096;
+        std::vector<u16> A(nb * 512), B(nb * 512);
+        for (size_t i = 0; i < A.size(); ++i) {
+            // products of very different magnitudes and signs, as the bf16x3 parts of one fp32 product have
+            const float ma = ldexpf(rnd() + 1.f, -(rand() % 18)) * (rand() & 1 ? 1.f : -1.f);
+            const float mb = ldexpf(rnd() + 1.f, (rand() % 12)) * (rand() & 1 ? 1.f : -1.f);
+            A[i] = bf16_rn(ma);
+            B[i] = bf16_rn(mb);
+        }
+        u16 *dA, *dB; float* dD;
+        hipMalloc(&dA, A.size() * 2); hipMalloc(&dB, B.size() * 2); hipMalloc(&dD, (size_t)nb * 1024 * 4);
+        hipMemcpy(dA, A.data(), A.size() * 2, hipMemcpyHostToDevice);
+        hipMemcpy(dB, B.data(), B.size() * 2, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_mfma_err, dim3(nb), dim3(64), 0, 0, dA, dB, dD);
+        std::vector<float> D((size_t)nb * 1024);
+        hipMemcpy(D.data(), dD, D.size() * 4, hipMemcpyDeviceToHost);
+        double worst_abs = 0, worst_res = 0;  // error / (2^-24 * sum |terms|)   and   error / (2^-24 * |result|)
+        long wrong_layout = 0;
+        for (int blk = 0; blk < nb; ++blk)
+            for (int r = 0; r < 32; ++r)
+                for (int cc = 0; cc < 32; ++cc) {
+                    double s = 0, sa = 0;
+                    for (int k = 0; k < 16; ++k) {
+                        const double p = (double)bf16_f(A[(size_t)blk * 512 + r * 16 + k]) * bf16_f(B[(size_t)blk * 512 + cc * 16 + k]);
+                        s += p; sa += fabs(p);
+                    }
+                    const double e = fabs((double)D[(size_t)blk * 1024 + r * 32 + cc] - s);
+                    if (e > 1e-3 * sa) ++wrong_layout;
+                    const double u = ldexp(1.0, -24);
+                    if (e / (u * sa) > worst_abs) worst_abs = e / (u * sa);
+                    if (fabs(s) > 0 && e / (u * fabs(s)) > worst_res) worst_res = e / (u * fabs(s));
+                }
+        printf("mfma accumulation (32x32x16 bf16, %d tiles): max |error| = %.3f * 2^-24 * sum|terms|   (%.1f * 2^-24 * |result| worst, cancellation included); layout mismatches %ld\n",
+               nb, worst_abs, worst_res, wrong_layout);
+    }
+    // ---- 3. throughput
+    {
+        constexpr int MH = 8;
+        const int ntiles = 8;
+        std::vector<u16> Bs(4 * MH * 32 * 16), As(ntiles * TILE_BYTES / 2);
+        for (auto& x : Bs) x = bf16_rn((rnd() - .5f) * 64.f);
+        for (auto& x : As) x = bf16_rn((rnd() - .5f) * 4.f);
+        u16 *dB, *dA; unsigned* dc;
+        hipMalloc(&dB, Bs.size() * 2); hipMalloc(&dA, As.size() * 2); hipMalloc(&dc, (size_t)cus * 8 * 4 * MH * 64 * 4);
+        hipMemcpy(dB, Bs.data(), Bs.size() * 2, hipMemcpyHostToDevice);
+        hipMemcpy(dA, As.data(), As.size() * 2, hipMemcpyHostToDevice);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int wpc = 2; wpc <= 4; ++wpc)
+            for (int epi = 0; epi < 3; ++epi) {
+                const dim3 g(cus * wpc), b(256);
+                const int reps = 64;
+                auto launch = [&] {
+                    if (epi == 0) hipLaunchKernelGGL((k_pipe<MH, 0>), g, b, ntiles * TILE_BYTES, 0, dB, dA, dc, ntiles, reps);
+                    else if (epi == 1) hipLaunchKernelGGL((k_pipe<MH, 1>), g, b, ntiles * TILE_BYTES, 0, dB, dA, dc, ntiles, reps);
+                    else hipLaunchKernelGGL((k_pipe<MH, 2>), g, b, ntiles * TILE_BYTES, 0, dB, dA, dc, ntiles, reps);
+                };
+                launch();
+                hipDeviceSynchronize();
+                float best = 1e9f;
+                for (int rep = 0; rep < 3; ++rep) {
+                    hipEventRecord(e0);
+                    for (int i = 0; i < 5; ++i) launch();
+                    hipEventRecord(e1);
+                    hipEventSynchronize(e1);
+                    float ms;
+                    hipEventElapsedTime(&ms, e0, e1);
+                    best = ms / 5 < best ? ms / 5 : best;
+                }
+                const double tests = (double)g.x * 4 * MH * 32 * ntiles * 32 * reps;
+                printf("workgroups/CU %d  MH=%d  %s: %8.3f ms  %7.2f T tests/s\n", wpc, MH,
+                       epi == 0 ? "clamp + add3            (1.5  op/test)" : epi == 1 ? "mix + perm + dot4 moments (1.75 op/test)" : "mix + dot2 moments        (2.0  op/test)",
+                       best, tests / best / 1e9);
+            }
+    }
+    return 0;
+}
