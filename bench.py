@@ -9,7 +9,12 @@ With --gpus N > 1 and no WORLD_SIZE in the environment the script launches ITSEL
 rank per GPU, rendezvous on 127.0.0.1), so `python bench.py --gpus 8` and the explicit launcher line are the same run.
 
 A "step" is one pass of the whole voting path (mask + 9-key-point vector field -> 9 key-points) over one batch of 32
-synthetic images per GPU, inputs resident in HBM.  Steps are independent batches, so they are issued round-robin on
+synthetic images per GPU, inputs resident in HBM.  The timed mode is the library's DEFAULT: exact mode -- matrix-pipe scoring
+whose inlier counts and winners EQUAL the reference kernels' (pvnet_vote.h, PVNET_F_LITERAL / PVNET_F_APPROX).
+The timed region -- barrier + synchronise, EXACTLY K steps, barrier + synchronise, max over ranks -- is run --regions
+times (default 15) and the MEDIAN region is reported as `value` / `ms_per_step` (a region of 20 steps lasts ~3 ms: one late
+stream moves a single region by several per cent); `regions` carries every region's rate, min, max and spread, and the
+GPU's clock and package power sampled while the regions ran.  Steps are independent batches, so they are issued round-robin on
 --streams HIP streams (default 6); `single_stream` in the output is the same K steps issued strictly one after the
 other (the per-batch latency a caller with ONE frame in flight sees).  With N > 1 every rank votes its own 32 images
 (weak scaling, no data-path collective) and its key-points leave through the path's one real exchange, an RCCL
@@ -17,23 +22,31 @@ all-gather of [32, 9, 2] per step -- bucketed: the key-points of --gather-bucket
 stream) are voted straight into a staging block and travel in ONE collective.  Rank 0 prints ONE JSON line.
 
 Besides the contract's fields the line carries
-  roofline      the dominant kernel (inlier scoring, score_mfma_kernel), compute bound.  Its duration is
+  roofline      the dominant kernel (inlier scoring, score_exact_kernel), compute bound.  Its duration is
                 measured live over >= 200 launches on the op's stream (pvnet_vote_v3_stage_repeat): every workgroup
                 stamps the device's constant-rate clock, max end - min start per launch = what a kernel trace reports
-                for it, free of launch gaps (the same launches between ONE hipEvent pair are reported beside it).  `achieved`/`peak`/`frac` price the matrix flops it EXECUTES (two
-                v_mfma_f32_32x32x16_bf16 per 32x32 pair tests = 64 flop per test) against the 2.5 PFLOP/s dense bf16
-                peak; `algorithmic_tflops` restates the same launch with SURVEY.md 8d's 12 fp32 flop per test,
-                `vs_fp32_vector_peak` / `vs_bf16_peak` price THAT against 157.3 TFLOP/s / 2.5 PFLOP/s;
-                `mfma_util` is the matrix pipe's busy fraction from the committed PMC pass
-                (SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x GRBM_GUI_ACTIVE per XCD), profiles/*_pmc.json).
+                for it, free of launch gaps (the same launches between ONE hipEvent pair are reported beside it).
+                `achieved` / `peak` / `frac` follow SURVEY.md 8d: ALGORITHMIC flops (12 fp32 flop per pair test x
+                `pair_tests_per_launch`) / `avg_launch_ms`, against the dense peak of the pipe the kernel runs on (bf16
+                MFMA, 2.5 PFLOP/s) -- recomputable from those three fields.  Side fields: `executed_*` (the matrix
+                flops actually issued: the bf16x3 split costs two v_mfma_f32_32x32x16_bf16 per 32x32 tests = 64 flop
+                per test), `vs_fp32_vector_peak` (the same algorithmic rate against the 157.3 TFLOP/s the path left),
+                `mfma_busy_frac` (matrix-pipe busy cycles / SIMD cycles from a committed PMC pass) and `traffic` (HBM
+                bytes per launch from committed FETCH_SIZE / WRITE_SIZE passes).  Everything that is read from a
+                committed profile instead of being measured in this run carries `*_from_committed_profile: <tag>`
+                next to the value and is null when that profile was taken from other kernel sources than this build.
   roofline_hbm  the whole path against HBM: `compulsory_bytes` (what any implementation must read: the masks + the
                 foreground vectors), `measured_bytes` (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE summed over the path's
                 kernels, profiles/*_traffic.json), and SURVEY.md 8d's dense-equivalent figure (the bytes a dense
                 implementation would stream) -- three different numerators over the same step time.
-  parity        the TIMED mode checked on the TIMED inputs after the timed region: fast-mode winners against literal
-                mode and against the plain-C oracle for every key-point of both input sets, key-points against the
-                C oracle (all) and the float64 oracle (first set).  The oracle only checks; it is never timed here.
-  literal_mode  votings/s of the bit-exact (reference float32 order) mode on the same inputs.
+  parity        the TIMED mode checked on the TIMED inputs after the timed region: every one of the 1024 inlier counts of
+                every key-point against literal mode (`counts_equal_literal`) and, for the first images, against the
+                REFERENCE'S OWN voting kernel compiled for gfx950 (`counts_equal_reference`, oracle/_ref); winners against
+                literal mode and the plain-C oracle; key-points against the C oracle (all) and the float64 oracle (first
+                set).  The oracle only checks; it is never timed here.
+  approx_mode   votings/s of PVNET_F_APPROX (the round-1/2 "fast" mode: no rounding-band re-evaluation, counts within a few
+                votes of the reference's) on the same inputs and streams -- what exactness costs.
+  literal_mode  votings/s of PVNET_F_LITERAL (the reference's float32 order for every pair on the VALU) on the same inputs.
   cpu_baseline  the plain-C restatement (oracle) timed on a bounded sample of the same workload.
 """
 import argparse
@@ -66,8 +79,9 @@ PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32
 MFMA_FLOP_PER_PAIR = 2 * (2 * 32 * 32 * 16) / (32 * 32)  # two 32x32x16 MFMAs (cr, dt) per 32x32 pair tests = 64
 N_SIMD = 256 * 4
 N_XCD = 8
-PATH_KERNELS = ("mask_bits_kernel", "compact_kernel", "hypothesis_kernel", "score_mfma_kernel",
-                "select_refine_kernel")
+SCORE_KERNEL = "score_exact_kernel"
+PATH_KERNELS = ("mask_bits_kernel", "compact_kernel", "hypothesis_kernel", SCORE_KERNEL, "select_refine_kernel")
+KERNEL_SOURCES = ("pvnet_amd/csrc/pvnet_vote.hip", "pvnet_amd/csrc/pvnet_rng.h", "include/pvnet_vote.h")
 
 
 def parse(argv=None):
@@ -79,7 +93,12 @@ def parse(argv=None):
                     help="untimed steps issued before the W warmup steps so that short runs do not measure the GPU's "
                          "clock ramp from idle (a step is ~0.12 ms: K=20 alone is a 2.4 ms burst)")
     ap.add_argument("--radius", type=int, default=40, help="disk radius of the synthetic object mask (tn ~ pi r^2)")
-    ap.add_argument("--buffers", type=int, default=2, help="distinct input sets cycled (2 x 786 MB > 256 MiB L3)")
+    ap.add_argument("--regions", type=int, default=15,
+                    help="how many times the timed K-step region is run; the MEDIAN region is reported (min / max / every "
+                         "region's rate alongside)")
+    ap.add_argument("--buffers", type=int, default=4,
+                    help="distinct input sets cycled: the TOUCHED bytes of a set are its masks (78.6 MB) + its foreground "
+                         "vectors (~11.6 MB), so 4 sets = 361 MB exceed the 256 MiB Infinity Cache")
     ap.add_argument("--clean", action="store_true", help="noise-free field (default: noisy, net-like background)")
     ap.add_argument("--streams", type=int, default=6,
                     help="HIP streams the steps are issued on round-robin (independent batches in flight)")
@@ -90,6 +109,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-parity", action="store_true", help="skip the post-run parity check of the timed mode")
+    ap.add_argument("--approx", action="store_true",
+                    help="DEVELOPMENT: time PVNET_F_APPROX as the main mode (the line's `mode` says so); for A/B runs against "
+                         "earlier rounds, whose default mode this was")
     ap.add_argument("--stub", action="store_true",
                     help="TEST ONLY (tests/test_bench_contract.py): gloo on CPU with a stub voter, to exercise the "
                          "launcher / process-group / gather plumbing without a GPU; the line says so and is no measurement")
@@ -127,35 +149,124 @@ def make_inputs(rank, nbuf, radius, noisy, dev):
     return sets
 
 
+def source_hash():
+    """sha1 over the kernel sources: a committed profile is only quoted when it was taken from these very sources"""
+    import hashlib
+    h = hashlib.sha1()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def newest_profile(suffix):
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)), key=os.path.getmtime)
     return files[-1] if files else None
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_traffic.json, written
-    by tools/rocpd_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes); None if absent."""
-    f = newest_profile("_traffic.json")
+def committed_profile(suffix):
+    """(tag, kernels dict, fresh) of the newest committed profiles/*<suffix>; fresh = taken from this build's sources.
+    Kernels are keyed by their FULL template instantiation (tools/rocpd_summary.py)."""
+    f = newest_profile(suffix)
     if not f:
-        return None
+        return None, {}, False
     try:
-        k = json.load(open(f))["kernels"][kernel]
-        return int((2.0 * k.get("fetch_kb", 0.0) + k.get("write_kb", 0.0)) * 1024)  # FETCH_SIZE x2: gfx950 correction
-    except (KeyError, ValueError):
-        return None
+        j = json.load(open(f))
+    except ValueError:
+        return None, {}, False
+    tag = os.path.basename(f)[:-len(suffix)]
+    return tag, j.get("kernels", {}), j.get("source_hash") == source_hash()
 
 
-def measured_mfma_util(kernel="score_mfma_kernel"):
-    """matrix-pipe busy fraction of `kernel` from the newest committed counter summary (profiles/*_pmc.json):
+def pick_instantiation(kernels, base):
+    """the instantiation of `base` with the most dispatches in the profiled run (the run also makes a few literal-mode
+    calls, whose instantiations must not be mistaken for the timed ones)"""
+    best = None
+    for name, k in kernels.items():
+        if name.split("<")[0] == base and (best is None or k.get("n", 0) > kernels[best].get("n", 0)):
+            best = name
+    return best
+
+
+def measured_traffic(base):
+    """HBM bytes per launch of kernel `base` from the newest committed PMC summary (profiles/*_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes); (None, tag) when absent or taken from other sources."""
+    tag, kernels, fresh = committed_profile("_traffic.json")
+    name = pick_instantiation(kernels, base)
+    if not fresh or name is None:
+        return None, tag, name
+    k = kernels[name]
+    return int((2.0 * k.get("fetch_kb", 0.0) + k.get("write_kb", 0.0)) * 1024), tag, name  # FETCH_SIZE x2: gfx950 correction
+
+
+def measured_mfma_busy(base=SCORE_KERNEL):
+    """matrix-pipe busy fraction of `base` from the newest committed counter summary (profiles/*_pmc.json):
     SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the chip's SIMDs) / (SIMDs x GRBM_GUI_ACTIVE per XCD)."""
-    f = newest_profile("_pmc.json")
-    if not f:
-        return None
+    tag, kernels, fresh = committed_profile("_pmc.json")
+    name = pick_instantiation(kernels, base)
+    if not fresh or name is None:
+        return None, tag
     try:
-        k = json.load(open(f))["kernels"][kernel]
-        return float(k["SQ_VALU_MFMA_BUSY_CYCLES"]) / (N_SIMD * float(k["GRBM_GUI_ACTIVE"]) / N_XCD)
+        k = kernels[name]
+        return float(k["SQ_VALU_MFMA_BUSY_CYCLES"]) / (N_SIMD * float(k["GRBM_GUI_ACTIVE"]) / N_XCD), tag
     except (KeyError, ValueError, ZeroDivisionError):
-        return None
+        return None, tag
+
+
+class GpuSampler:
+    """shader clock and package power of one GPU, sampled from sysfs (amdgpu hwmon) by a thread while the timed regions
+    run -- no subprocess, nothing on the GPU.  Absent files (other driver versions) simply give no samples."""
+
+    def __init__(self, index, period=0.005):
+        import threading
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self.freq = self.power = None
+        mons = []
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            try:
+                if open(os.path.join(d, "name")).read().strip() == "amdgpu":
+                    mons.append(d)
+            except OSError:
+                pass
+        if mons:
+            d = mons[index % len(mons)]
+            for f in ("freq1_input",):
+                if os.path.exists(os.path.join(d, f)):
+                    self.freq = os.path.join(d, f)
+            for f in ("power1_average", "power1_input"):
+                if os.path.exists(os.path.join(d, f)):
+                    self.power = os.path.join(d, f)
+                    break
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError, TypeError):
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.samples.append((self._read(self.freq) if self.freq else None, self._read(self.power) if self.power else None))
+            time.sleep(self.period)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=1.0)
+
+    def summary(self):
+        def stat(xs, scale):
+            xs = [x * scale for x in xs if x is not None]
+            return {"mean": sum(xs) / len(xs), "min": min(xs), "max": max(xs), "samples": len(xs)} if xs else None
+        return {"sclk_mhz": stat([s[0] for s in self.samples], 1e-6), "power_w": stat([s[1] for s in self.samples], 1e-6),
+                "source": "amdgpu hwmon (sysfs freq1_input / power1_average), sampled every "
+                          f"{self.period * 1e3:.0f} ms while the timed regions ran"}
 
 
 def usable_cores():
@@ -221,31 +332,51 @@ def cpu_baseline(sets, seconds):
                       f"cpus, {cores} usable under its cgroup quota / affinity); {n1} images on one core"}
 
 
-def parity_check(sets, rank, o64_images=BATCH):
+def parity_check(sets, rank, o64_images=BATCH, ref_images=8, max_sets=2):
     """The timed mode on the timed inputs, checked after the timed region (the oracle is the CHECKER here, nothing of
-    it is timed or shipped).  Step s (s = 0 .. buffers-1) is exactly the s-th timed step: input set s, seed SEED0 + s,
-    this rank's image offset.  Winners: fast (timed) mode vs literal mode vs the plain-C oracle, every key-point.
-    Key-points: fast mode vs the C oracle (float32 votes, float64 least squares) everywhere and vs the float64 numpy
-    oracle on the first `o64_images` images of set 0.  north_star tolerance: 1e-3 px."""
+    it is timed or shipped).  Step s (s = 0 .. max_sets-1) is exactly the s-th timed step: input set s, seed SEED0 + s,
+    this rank's image offset.
+      * integer products: all HN inlier counts of every (image, key-point) of the timed (exact) mode against literal mode
+        (`counts_equal_literal`: how many of the (image, key-point) count vectors are EQUAL) and, for the first
+        `ref_images` images of set 0, against the reference's OWN voting kernel compiled for gfx950 (oracle/_ref,
+        `counts_equal_reference`); winners against literal mode and the plain-C oracle;
+      * key-points: against the C oracle (float32 votes, float64 least squares) everywhere and against the float64 numpy
+        oracle on the first `o64_images` images of set 0.  north_star tolerance: 1e-3 px."""
     from concurrent.futures import ThreadPoolExecutor
-    from oracle import cref
+    from oracle import cref, refkernels
     from oracle import ransac_voting_oracle as O
     cref.build()
     cores = usable_cores()
-    tot = fl_eq = lo_eq = fo_eq = 0
+    tot = fl_eq = lo_eq = fo_eq = cnt_eq = 0
     max_px_c = max_px_lit = 0.0
-    worst_flip_px = 0.0
-    worst_flip_dcount = 0
-    for s, (m, v, mask, planar) in enumerate(sets):
+    max_count_diff = 0
+    ref_eq = ref_tot = 0
+    for s, (m, v, mask, planar) in enumerate(sets[:max_sets]):
         fast, df = voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=SEED0 + s,
                                                  image_offset=rank * BATCH, return_debug=True)
         fast = fast.cpu().numpy()
         wf = df["win"].cpu().numpy().copy()
-        cf = df["counts"].cpu().numpy().copy()
+        cf = df["counts"].clone()
+        if s == 0 and ref_images > 0 and refkernels.available("off"):
+            for bi in range(min(ref_images, BATCH)):  # the reference's kernel on the path's own compacted pixels
+                tn = int(df["tn"][bi])
+                rec = df["rec"][bi, :, :tn]
+                coords = rec[0, :, 0:2].contiguous()
+                direct = rec[:, :, 2:4].permute(1, 0, 2).contiguous()
+                hyp = df["hyp"][bi].permute(1, 0, 2).contiguous()
+                cref_counts = torch.zeros((HN, VN), dtype=torch.int32, device=m.device)
+                stp = max(1, (1 << 27) // (VN * max(tn, 1)))
+                for h0 in range(0, HN, stp):
+                    inl = refkernels.voting_for_hypothesis(direct, coords, hyp[h0:h0 + stp].contiguous(), THRESH)
+                    cref_counts[h0:h0 + stp] = inl.sum(2, dtype=torch.int32)
+                ref_eq += int((cf[bi].T == cref_counts).all(0).sum())
+                ref_tot += VN
         lit, dl = voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=SEED0 + s,
                                                 image_offset=rank * BATCH, literal=True, return_debug=True)
         lit = lit.cpu().numpy()
         wl = dl["win"].cpu().numpy().copy()
+        cnt_eq += int((cf == dl["counts"]).all(2).sum())
+        max_count_diff = max(max_count_diff, int((cf - dl["counts"]).abs().max()))
         vnp = synth.planar_to_vertex_view(planar)
         fg = O.foreground(mask)
 
@@ -265,17 +396,14 @@ def parity_check(sets, rank, o64_images=BATCH):
         fo_eq += int((wf[:, :, 0] == wi).sum())
         max_px_c = max(max_px_c, float(np.abs(fast - ref).max()))
         max_px_lit = max(max_px_lit, float(np.abs(fast - lit).max()))
-        flip = wf[:, :, 0] != wl[:, :, 0]
-        if flip.any():  # a near-tie that the two arithmetics order differently: bound what it costs
-            worst_flip_px = max(worst_flip_px, float(np.abs(fast - lit)[flip].max()))
-            bi, ki = np.nonzero(flip)
-            dc = np.abs(cf[bi, ki, wf[bi, ki, 0]] - cf[bi, ki, wl[bi, ki, 0]])
-            worst_flip_dcount = max(worst_flip_dcount, int(dc.max()))
-    out = {"keypoints_checked": tot, "fast_winners_equal_literal": fl_eq, "literal_winners_equal_c_oracle": lo_eq,
-           "fast_winners_equal_c_oracle": fo_eq, "winners_equal": bool(tot and fl_eq == tot and lo_eq == tot),
-           "max_px_fast_vs_c_oracle": max_px_c, "max_px_fast_vs_literal": max_px_lit,
-           "winner_flips": {"n": tot - fl_eq, "max_px": worst_flip_px, "max_count_gap": worst_flip_dcount},
-           "tolerance_px": 1e-3}
+    out = {"keypoints_checked": tot, "hypotheses_per_keypoint": HN,
+           "counts_equal_literal": cnt_eq, "max_count_diff_vs_literal": max_count_diff,
+           "counts_equal_reference": ref_eq if ref_tot else None, "reference_keypoints_checked": ref_tot,
+           "reference": "oracle/_ref/libpvnet_refkernels.so: ransac_voting_kernel.cu:88-126 compiled for gfx950 from the "
+                        "reference tree" if ref_tot else "oracle/_ref not built on this box",
+           "winners_equal_literal": fl_eq, "literal_winners_equal_c_oracle": lo_eq, "winners_equal_c_oracle": fo_eq,
+           "winners_equal": bool(tot and fl_eq == tot and lo_eq == tot),
+           "max_px_vs_c_oracle": max_px_c, "max_px_vs_literal": max_px_lit, "tolerance_px": 1e-3}
     if o64_images > 0:
         m, v, mask, planar = sets[0]
         k = min(o64_images, BATCH)
@@ -285,8 +413,10 @@ def parity_check(sets, rank, o64_images=BATCH):
                                              image_offset=rank * BATCH).cpu().numpy()
         out["max_px_vs_oracle64"] = float(np.abs(fast[:k] - o64).max())
         out["oracle64_images"] = k
-    out["pass"] = bool(out["winners_equal"] and max_px_c <= 1e-3 and out.get("max_px_vs_oracle64", 0.0) <= 1e-3)
-    out["mode"] = "fast (bf16x3 MFMA scoring): the mode the timed region ran"
+    out["pass"] = bool(out["winners_equal"] and cnt_eq == tot and (ref_tot == 0 or ref_eq == ref_tot) and
+                       max_px_c <= 1e-3 and out.get("max_px_vs_oracle64", 0.0) <= 1e-3)
+    out["mode"] = "exact (the library's default: bf16x3 MFMA scoring + literal re-evaluation inside the rounding band): " \
+                  "the mode the timed region ran"
     return out
 
 
@@ -332,6 +462,9 @@ def main(argv=None):
     # rewritten only after the gather that read it has completed (event on the communication stream).
     nstreams = max(1, a.streams)
     streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
+    ws_bytes = voting.vote_layout(BATCH, H, W, VN, HN, 30000).total_bytes
+    spaces = [torch.empty(ws_bytes, dtype=torch.uint8, device=dev) for _ in range(nstreams)]  # one workspace per stream:
+    # calls on one stream are ordered, so they share it; nothing is allocated inside the timed regions
     G = max(1, a.gather_bucket if a.gather_bucket > 0 else nstreams)
     if dist is not None:
         comm = torch.cuda.Stream(dev)
@@ -361,21 +494,23 @@ def main(argv=None):
         bucket["n"] += 1
         bucket["fill"] = 0
 
-    def step(i, ns=nstreams, **kw):
+    def step(i, ns=nstreams, mode=None, **kw):
         m, v, _, _ = sets[i % len(sets)]
+        mode = mode or {}
         if kw:  # profiled / debug calls: current stream, synchronising
             return voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=SEED0 + i,
-                                                 image_offset=rank * BATCH, **kw)
+                                                 image_offset=rank * BATCH, **mode, **kw)
         st = streams[i % ns]
         with torch.cuda.stream(st):
             if dist is None:
                 return voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=SEED0 + i,
-                                                     image_offset=rank * BATCH)
+                                                     image_offset=rank * BATCH, workspace=spaces[i % ns], **mode)
             blk, j = bucket["n"] % 2, bucket["fill"]
             if sent[blk] is not None:
                 st.wait_event(sent[blk])  # the gather that last read this block has completed
             out = voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=SEED0 + i,
-                                                image_offset=rank * BATCH, out=staging[blk][j])
+                                                image_offset=rank * BATCH, out=staging[blk][j], workspace=spaces[i % ns],
+                                                **mode)
             voted[blk][j].record(st)
         bucket["fill"] += 1
         if bucket["fill"] == G:
@@ -401,14 +536,15 @@ def main(argv=None):
             barrier()
         torch.cuda.synchronize(dev)
 
-    def timed(ns, steps=None, **kw):
+    def timed(ns, steps=None, mode=None, **kw):
+        """ONE timed region: warm-up, fence, exactly `steps` steps, fence; max over ranks"""
         steps = a.steps if steps is None else steps
         for i in range(a.warmup if not kw else min(a.warmup, 3)):
-            step(i, ns, **kw)
+            step(i, ns, mode, **kw)
         fence()
         t0 = time.perf_counter()
         for i in range(steps):
-            step(i, ns, **kw)
+            step(i, ns, mode, **kw)
         fence()
         dt_local = time.perf_counter() - t0
         dt = dt_local
@@ -418,6 +554,16 @@ def main(argv=None):
             dt = float(t.item())
         return dt, dt_local
 
+    def regions(ns, mode=None, n=None):
+        """the timed region `n` times; returns the per-region (max-over-ranks, local) durations"""
+        return [timed(ns, mode=mode) for _ in range(max(1, a.regions if n is None else n))]
+
+    def median(xs):
+        xs = sorted(xs)
+        k = len(xs) // 2
+        return xs[k] if len(xs) % 2 else 0.5 * (xs[k - 1] + xs[k])
+
+    MAIN = {"approx": True} if a.approx else {}
     t_pre = time.perf_counter()                      # device pre-warm (untimed, reported in config.prewarm_s)
     i_pre = 0
     while time.perf_counter() - t_pre < a.prewarm_seconds:
@@ -428,8 +574,15 @@ def main(argv=None):
             i_pre += 1
         torch.cuda.synchronize(dev)
     fence()
-    dt, dt_local = timed(nstreams)                   # the headline: K steps, independent batches on S streams
-    dt1, _ = timed(1) if nstreams > 1 else (dt, dt_local)  # the same K steps strictly one after the other
+    with GpuSampler(local) as sampler:
+        runs = regions(nstreams, mode=MAIN)          # the headline: R regions of K steps, independent batches on S streams
+    dts = [r[0] for r in runs]
+    dt = median(dts)
+    dt_local = median([r[1] for r in runs])
+    runs1 = regions(1, mode=MAIN, n=max(3, a.regions // 3)) if nstreams > 1 else runs  # the same K steps one after the other
+    dt1 = median([r[0] for r in runs1])
+    runs_apx = regions(nstreams, mode={"approx": True}, n=max(3, a.regions // 3))  # PVNET_F_APPROX on the same inputs
+    dt_apx = median([r[0] for r in runs_apx])
 
     per_rank = [BATCH * a.steps / dt_local]
     gather_ms = None
@@ -466,80 +619,107 @@ def main(argv=None):
     score_b2b_ms = float(np.mean([x[1] for x in both]))  # event pair around back-to-back launches (+ launch boundary)
     score_s = score_ms * 1e-3
     path_s = sum(stage_ms.values()) * 1e-3
-    lit_dt, _ = timed(1, steps=5, literal=True)      # the bit-exact mode, a few synchronising calls: per-call latency
+    lit_dt, _ = timed(1, steps=5, mode={"literal": True})  # literal mode: a few calls on one stream
+
+    seen = None
+    if dist is not None:  # which ranks / devices took part (RCCL really spans them): every rank reports its device
+        mine = torch.tensor([rank, local, torch.cuda.current_device()], dtype=torch.int64, device=dev)
+        allm = torch.empty((world, 3), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allm, mine)
+        seen = allm.tolist()
 
     if rank == 0:
         votings_per_s = world * BATCH * a.steps / dt
         step_s = dt / a.steps
+        rates = [world * BATCH * a.steps / x for x in dts]
         exec_tflops = MFMA_FLOP_PER_PAIR * pairs / score_s / 1e12
         alg_tflops = FLOP_PER_PAIR * pairs / score_s / 1e12
         compulsory = BATCH * H * W * 8 + tn_per_batch * VN * 2 * 4  # the masks + the foreground vectors, per batch
-        traffic = {k: measured_traffic(k) for k in PATH_KERNELS}
-        mfma_util = measured_mfma_util()
-        mfma_util_s = "n/a" if mfma_util is None else f"{mfma_util:.2f}"
-        measured = sum(v for v in traffic.values() if v) if any(traffic.values()) else None
+        traffic, traffic_tag, traffic_names = {}, None, {}
+        for k in PATH_KERNELS:
+            traffic[k], traffic_tag, traffic_names[k] = measured_traffic(k)
+        busy, busy_tag = measured_mfma_busy()
+        measured = sum(v for v in traffic.values() if v) if all(traffic.values()) else None
+        L = voting.vote_layout(BATCH, H, W, VN, HN, 30000)
         res = {
             "metric": "RANSAC votings/s (480x640, 9 kpts, batch 32) + HBM GB/s vs roofline",
             "value": votings_per_s, "unit": "votings/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "regions": {"runs": len(dts), "reported": "median", "min": min(rates), "max": max(rates),
+                        "spread": (max(rates) - min(rates)) / votings_per_s, "values": rates,
+                        "note": "the timed region (fence, exactly K steps, fence; max over ranks) run `runs` times; value "
+                                "and ms_per_step are the MEDIAN region",
+                        "gpu": sampler.summary()},
+            "mode": "APPROX (--approx, development A/B only)" if a.approx else
+                    "exact (library default): inlier counts and winners equal the reference kernels'",
             "single_stream": {"value": world * BATCH * a.steps / dt1, "ms_per_step": dt1 / a.steps * 1e3,
+                              "runs": len(runs1),
                               "note": "the same K steps issued on one stream: per-batch latency of the whole path"},
+            "approx_mode": {"value": world * BATCH * a.steps / dt_apx, "unit": "votings/s",
+                            "ms_per_step": dt_apx / a.steps * 1e3, "runs": len(runs_apx),
+                            "note": "PVNET_F_APPROX (the round-1/2 'fast' mode, counts within a few votes of the "
+                                    "reference's) on the same inputs and streams: what the default mode's exactness costs"},
             "literal_mode": {"value": world * BATCH * 5 / lit_dt, "unit": "votings/s", "ms_per_step": lit_dt / 5 * 1e3,
-                             "note": "PVNET_F_LITERAL: the reference's float32 operation order, bit-exact with its "
-                                     "kernels (5 synchronising calls on one stream)"},
+                             "note": "PVNET_F_LITERAL: the reference's float32 operation order for every pair on the "
+                                     "VALU (5 calls on one stream)"},
             "per_rank_votings_per_s": per_rank, "gather_ms": gather_ms,
             "gather_bucket_steps": G if dist is not None else None,
-            "dtype": "bf16x3 products, f32 accumulate (f32-equivalent; refinement f64)", "data": "synthetic",
+            "rccl_ranks_seen": len(seen) if seen else None,
+            "rank_devices": [{"rank": r, "local_rank": l, "device": d} for r, l, d in seen] if seen else None,
+            "dtype": "f32 decisions (bf16x3 MFMA products, f32 accumulate; pairs inside the f32 rounding band re-evaluated "
+                     "in the reference's f32 order); refinement f64",
+            "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[2]: batch=32 synthetic 480x640 fields per GPU, 9 keypoints, "
                                    "1024 hypotheses, inlier_thresh 0.99, int64 mask, planar strided field",
                        "batch_per_gpu": BATCH, "global_batch": world * BATCH, "h": H, "w": W, "vn": VN, "hn": HN,
                        "mask_radius": a.radius, "mean_foreground_px": tn_per_batch / BATCH,
                        "field": "clean" if a.clean else "noisy (0.05 rad + 10% outliers), N(0,1) background",
-                       "input_sets_cycled": len(sets), "streams": nstreams, "prewarm_s": a.prewarm_seconds,
+                       "input_sets_cycled": len(sets),
+                       "touched_input_bytes": int(len(sets) * compulsory),
+                       "streams": nstreams, "prewarm_s": a.prewarm_seconds,
                        "parallelism": f"images sharded over {world} GPU(s); steps issued round-robin on {nstreams} "
                                       f"HIP stream(s) per GPU"},
-            "roofline": {"kernel": "score_mfma_kernel", "bound": "mfma",
-                         "achieved": exec_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": exec_tflops / PEAK_BF16_TFLOPS,
-                         "traffic": traffic["score_mfma_kernel"],
+            "roofline": {"kernel": f"{SCORE_KERNEL}<{L.wg_g * L.hpl // 2}, ...>", "bound": "mfma",
+                         "achieved": alg_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": alg_tflops / PEAK_BF16_TFLOPS,
+                         "definition": "SURVEY.md 8d: achieved = algorithmic_flop_per_pair x pair_tests_per_launch / "
+                                       "avg_launch_ms; peak = dense bf16 MFMA, the pipe the kernel runs on",
+                         "algorithmic_flop_per_pair": FLOP_PER_PAIR, "pair_tests_per_launch": pairs,
                          "avg_launch_ms": score_ms, "launches_timed": reps * len(sets),
                          "avg_launch_ms_back_to_back_events": score_b2b_ms,
                          "timing": "avg_launch_ms = max end - min start of the kernel's workgroups on the device's "
                                    "constant-rate clock, averaged over the launches (pvnet_vote_v3_stage_repeat): the "
                                    "duration a kernel trace reports; the event figure adds the dependent-launch boundary",
-                         "pair_tests_per_launch": pairs, "pair_tests_per_s": pairs / score_s,
-                         "flop_per_pair_executed": MFMA_FLOP_PER_PAIR,
-                         "algorithmic_flop_per_pair": FLOP_PER_PAIR, "algorithmic_tflops": alg_tflops,
+                         "pair_tests_per_s": pairs / score_s,
                          "vs_fp32_vector_peak": alg_tflops / PEAK_F32_TFLOPS,
-                         "vs_bf16_peak": alg_tflops / PEAK_BF16_TFLOPS,
-                         "mfma_util": mfma_util,
-                         "mfma_util_source": os.path.basename(newest_profile("_pmc.json") or "") or None,
-                         "note": f"exec {exec_tflops:.0f} TF = {exec_tflops / PEAK_BF16_TFLOPS:.2f} bf16 peak; algorithmic "
-                                 f"{alg_tflops:.0f} TF = {alg_tflops / PEAK_F32_TFLOPS:.2f}x fp32 vector = "
-                                 f"{alg_tflops / PEAK_BF16_TFLOPS:.3f} bf16; mfma_util {mfma_util_s}.  "
-                                 "frac = EXECUTED matrix flops (bf16x3 split, K = 15 of 16 slots: 64 flop per test) / "
-                                 "2.5 PF; the same launch is 12 algorithmic fp32 flop per test (SURVEY 8d) = "
-                                 "vs_fp32_vector_peak of the vector peak it left for the matrix pipe = vs_bf16_peak of "
-                                 "the bf16 peak; mfma_util = matrix-pipe busy cycles / SIMD cycles (PMC)"},
+                         "executed_flop_per_pair": MFMA_FLOP_PER_PAIR, "executed_tflops": exec_tflops,
+                         "executed_frac": exec_tflops / PEAK_BF16_TFLOPS,
+                         "traffic": traffic[SCORE_KERNEL], "traffic_from_committed_profile": traffic_tag,
+                         "mfma_busy_frac": busy, "mfma_busy_frac_from_committed_profile": busy_tag,
+                         "note": "frac prices the 12 algorithmic fp32 flop of a pair test (SURVEY 8d); the kernel EXECUTES "
+                                 "64 matrix flop per test (bf16x3 split: two v_mfma_f32_32x32x16_bf16 per 32x32 tests, K = "
+                                 "15 of 16 slots) = executed_frac, and 2.5 VALU operations per test for the vote and the "
+                                 "rounding band, which is what binds it (DESIGN.md section 5)"},
             "roofline_hbm": {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "compulsory_bytes": compulsory, "compulsory_gbs": compulsory / step_s / 1e9,
                              "compulsory_frac": compulsory / step_s / 1e9 / PEAK_HBM_GBS,
-                             "measured_bytes": measured,
+                             "measured_bytes": measured, "measured_bytes_from_committed_profile": traffic_tag,
                              "measured_gbs": measured / step_s / 1e9 if measured else None,
                              "measured_frac": measured / step_s / 1e9 / PEAK_HBM_GBS if measured else None,
                              "measured_over_compulsory": measured / compulsory if measured else None,
-                             "traffic_per_kernel": traffic,
+                             "traffic_per_kernel": traffic, "traffic_kernel_instantiations": traffic_names,
                              "dense_equivalent_bytes": BYTES_PER_VOTING * BATCH,
                              "dense_equivalent_gbs": BYTES_PER_VOTING * BATCH / step_s / 1e9,
                              "dense_equivalent_frac": BYTES_PER_VOTING * BATCH / step_s / 1e9 / PEAK_HBM_GBS,
                              "path_ms_serial": path_s * 1e3,
-                             "note": f"compulsory {compulsory / 1e6:.0f} MB, measured {(measured or 0) / 1e6:.0f} MB per batch; "
-                                     "compulsory = int64 masks + foreground vectors (what must cross HBM); measured = "
-                                     "rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the five kernels (committed PMC pass); "
-                                     "dense_equivalent = SURVEY 8d's 24 576 072 B per voting, the bytes a dense "
-                                     "implementation streams -- NOT achieved bandwidth: the path never reads the "
-                                     "background of the field.  All three over the multi-stream step time."},
+                             "note": "compulsory = int64 masks + foreground vectors (what must cross HBM); measured = "
+                                     "rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the five kernels (committed PMC passes, null "
+                                     "when they were taken from other kernel sources than this build); dense_equivalent = "
+                                     "SURVEY 8d's 24 576 072 B per voting, the bytes a dense implementation streams -- NOT "
+                                     "achieved bandwidth: the path never reads the background of the field.  All three "
+                                     "over the multi-stream step time."},
             "stage_ms": stage_ms,
+            "kernel_source_hash": source_hash(),
         }
         if not a.no_parity:
             try:

@@ -26,6 +26,16 @@ extern "C" {
 void uncertainty_pnp(double* pts2d, double* pts3d, double* wgt2d, double* K, double* init_rt, double* result_rt,
                      int pn);
 
+/* The cost function the solver minimises, exposed so that it can be pinned to the reference's: residuals [2 pn] =
+ * (wxx dx + wxy dy, wxy dx + wyy dy) per point with (dx, dy) = projection - observation, exactly
+ * ReprojectionErrorArray::operator() (uncertainty_pnp.cpp:16-35), and -- when `jacobian` is not NULL -- its analytic
+ * Jacobian [2 pn][6] with respect to (angle-axis, translation), which is what ceres::AutoDiffCostFunction derives from
+ * that functor by Jets (uncertainty_pnp.cpp:46-47).  wgt2d may be NULL (identity).  Returns 0, 1 if a point falls on the
+ * camera plane (outputs undefined), -1 on bad arguments.  tests/test_pnp.py compares both with the reference's functor
+ * compiled from the reference tree against its vendored ceres/jet.h + rotation.h (oracle/_ref/libpvnet_refpnp.so). */
+int pvnet_pnp_evaluate(const double* pts2d, const double* pts3d, const double* wgt2d, const double* K, const double* rt,
+                       int pn, double* residuals, double* jacobian);
+
 /* The same solver with a report.  wgt2d may be NULL (identity weights = the unweighted reprojection error that
  * cv2.solvePnP's ITERATIVE flag minimises).  Returns the number of LM iterations taken (>= 0), or -1 on bad
  * arguments.  final_cost (may be NULL) receives 0.5 * sum of squared weighted residuals. */

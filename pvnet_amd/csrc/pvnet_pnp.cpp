@@ -241,6 +241,13 @@ bool dlt_pose(const double* x2, const double* x3, const double* K, int pn, doubl
 
 extern "C" {
 
+int pvnet_pnp_evaluate(const double* pts2d, const double* pts3d, const double* wgt2d, const double* K, const double* rt,
+                       int pn, double* residuals, double* jacobian) {
+    if (!pts2d || !pts3d || !K || !rt || !residuals || pn < 1 || pn > MAX_PN) return -1;
+    const Problem P{pts2d, pts3d, wgt2d, K, pn};
+    return evaluate(P, rt, residuals, jacobian) ? 0 : 1;
+}
+
 int pvnet_pnp_refine(const double* pts2d, const double* pts3d, const double* wgt2d, const double* K,
                      const double* init_rt, double* result_rt, int pn, int max_iterations, double* final_cost) {
     if (!pts2d || !pts3d || !K || !init_rt || !result_rt || pn < 3 || pn > MAX_PN) return -1;

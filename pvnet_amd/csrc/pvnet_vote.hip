@@ -282,6 +282,8 @@ __device__ __forceinline__ void b_col(float x, float y, uint4& lo, uint4& hi) {
 // rows are sent as zeros: a' = b' = 0 flags every cell they touch, which is then decided by the reference's arithmetic
 // itself, whatever that does.  Zero records (padding, |u| < 1e-6) and NaN / Inf directions never vote in the reference;
 // their rows are zero except for the spare 16th K slot, A[15] = -4 against B[15] = 1: a' = b' = -4, no vote, no flag.
+// (Exact mode compacts like literal mode: records keep the RAW direction even below the gate, because the reference's
+// hypothesis generation reads it -- a 1e-7 direction paired with a 1e12 one has a determinant far above ITS gate.)
 constexpr float BAND_TARGET = 0.9f;             // |s sigma m| inside the band (proof obligation: < 1 with the float roundings of the scales)
 constexpr float BAND_FAR = 0x1p61f;             // beyond this the reference's float32 squares may overflow
 __device__ __forceinline__ float band_rho(int tn) {  // the length scale that splits |d| <= (R + rho)(1 + r / rho)
@@ -313,7 +315,12 @@ __device__ __forceinline__ void a_rows_exact(float4 q, float tau, float ox, floa
     const float m = fmaxf(fabsf(q.z), fabsf(q.w));
     const uint32_t e = (__float_as_uint(m) >> 23) & 0xFFu;
     const bool finite = fabsf(q.z) <= 3.4028235e38f && fabsf(q.w) <= 3.4028235e38f;  // false for NaN and Inf
-    if (!(m > 0.f) || !finite) {  // zero record (padding, |u| < 1e-6), NaN or Inf direction: the reference never votes
+    // the reference never votes for: padding (zero record), NaN / Inf directions, and |u| below its 1e-6 gate -- decided by
+    // the gate's own arithmetic (norm1_literal), which only directions within a factor two of the gate need: records keep
+    // the RAW direction in exact mode, as hypothesis generation needs it
+    bool dead = !(m > 0.f) || !finite;
+    if (!dead && m <= 2.0e-6f) dead = norm1_literal(q.z, q.w) <= kF1e6;  // (m > 2e-6 implies norm1 > 1e-6 in any rounding)
+    if (dead) {
         ahi.w = bhi.w = pk(0u, never);
         return;
     }
@@ -322,8 +329,9 @@ __device__ __forceinline__ void a_rows_exact(float4 q, float tau, float ox, floa
     const float u1x = q.z * pre, u1y = q.w * pre;               // exact
     const float g = __builtin_amdgcn_rsqf(fmaf(u1y, u1y, u1x * u1x));
     const float cx = q.x - ox, cy = q.y - oy;                   // exact: integer pixel coordinates
-    const float r = __builtin_sqrtf(fmaf(cy, cy, cx * cx));
-    const float gs = g * (rho / (rho + r)) * 0.9997f;           // |M| = |u1| gs <= rho / (rho + r)   (rsq, sqrt, divide: 1 ulp each)
+    const float r = __builtin_amdgcn_sqrtf(fmaf(cy, cy, cx * cx));            // (v_sqrt_f32 / v_rcp_f32: 1 ulp each --
+    const float gs = g * rho * __builtin_amdgcn_rcpf(rho + r) * 0.9997f;      //  an upper bound is all that is needed)
+    // |M| = |u1| gs <= rho / (rho + r)
     const float Mx = u1x * gs, My = u1y * gs;
     const float Tx = tau * Mx, Ty = tau * My;
     const float Ec = fmaf(cx, My, -cy * Mx);                    // cr = hx My - hy Mx - Ec
@@ -904,6 +912,13 @@ __device__ __forceinline__ void vote8(unsigned& acc, float d0, float c0, float d
         : "v"(d0), "v"(c0), "v"(d1), "v"(c1), "v"(d2), "v"(c2), "v"(d3), "v"(c3), "v"(d4), "v"(c4), "v"(d5), "v"(c5),
           "v"(d6), "v"(c6), "v"(d7), "v"(c7));
 }
+// v + (the other half-wave's v): lanes l and l ^ 32 hold different pixel rows of one hypothesis column.  gfx950's
+// v_permlane32_swap exchanges the upper row of one operand with the lower row of the other in the VALU -- no trip through
+// the LDS crossbar as __shfl_xor (ds_bpermute) takes, eight times per work item.
+__device__ __forceinline__ int half_wave_sum(int v) {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)(r[0] + r[1]);
+}
 constexpr int VOTE_WRAP = 512;  // vote8 accumulators hold their count mod 512
 __device__ __forceinline__ int votes_of(unsigned acc) { return (int)(((acc >> 23) * 383u) & 511u); }
 
@@ -994,7 +1009,7 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
 #pragma unroll
         for (int t = 0; t < MH; ++t) {
             const int ci = votes_of(cnt[t]);
-            const int c = ci + __shfl_xor(ci, 32, 64);  // the half-waves hold different rows of the column
+            const int c = half_wave_sum(ci);  // the half-waves hold different rows of the column
             if (P.atomic_counts) {
                 if (half == 0 && c > 0) atomicAdd(P.counts + bk * P.hn_pad + h0 + t * 32 + col, c);
             } else if (half == 0) {
@@ -1046,7 +1061,7 @@ __device__ __forceinline__ void vote8ab(unsigned& acc, float& dm, float a0, floa
 constexpr float BAND_CLEAN = 1.0f;     // a cell whose minimum |a'|, |b'| reaches this holds no test inside the band
 
 // FOLD1 = false: one cell per (lane, hypothesis tile) and work item -- the minimum runs over all the item's pixel tiles
-//                (cheapest epilogue; right when flagged cells are rare: thresh <= ~0.995 on unit fields);
+//                (cheapest epilogue; right when flagged cells are very rare: loose thresholds, band_fold1());
 // FOLD1 = true:  one cell per (lane, hypothesis tile, PIXEL tile) -- the test is made after every step, so a flagged cell
 //                costs 16 literal tests instead of 16 * tiles (right when the threshold sits inside the field's noise).
 template <int MH, bool FOLD1, bool TIMED>
@@ -1060,7 +1075,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     const int npx = P.wg_s * P.chunk, ntiles = npx >> 5;
     uint4* s_t = reinterpret_cast<uint4*>(smem);                        // A tiles: ntiles x 2 KB  (A_a rows | A_b rows)
     float4* s_raw = reinterpret_cast<float4*>(s_t + ntiles * TILE_U4);  // raw records of the pixel group
-    unsigned* s_cells = reinterpret_cast<unsigned*>(s_raw + npx);       // flagged cells of this item (4 * MH * 64 slots)
+    float2* s_hyp = reinterpret_cast<float2*>(s_raw + npx);             // the item's 4 * MH * 32 hypotheses (for the flagged cells)
+    unsigned* s_cells = reinterpret_cast<unsigned*>(s_hyp + 4 * MH * 32);  // flagged cells of this item (4 * MH * 64 slots)
     __shared__ int s_ncell;
     const int32_t* __restrict__ ctrl = P.ctrl;
     const int total = ctrl[P.b * CTRL_STRIDE];
@@ -1079,15 +1095,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         const int hslice = hq * 4 * MH * 32;            // first hypothesis of this work item
         const int h0 = hslice + wave * MH * 32;         // this wave's first hypothesis
 
+        __syncthreads();  // the previous item's tiles, raw records and cell list have been consumed
+        if (threadIdx.x == 0) s_ncell = 0;
+        int tid = threadIdx.x;  // opaque copies of the thread index: what staging and re-evaluation derive from it is
+        asm volatile("" : "+v"(tid));  // recomputed per item instead of staying in VGPRs across the scoring loop
+        float2 hreg[(4 * MH * 32 + 255) / 256];  // the item's hypotheses: loaded now, parked in LDS after the staging arithmetic
+#pragma unroll
+        for (int j = 0; j < (4 * MH * 32 + 255) / 256; ++j)
+            hreg[j] = (tid + 256 * j < 4 * MH * 32) ? P.hyp[bk * P.hn_pad + hslice + tid + 256 * j] : make_float2(0.f, 0.f);
         bf16x8 B[MH];
 #pragma unroll
         for (int t = 0; t < MH; ++t) {
             const uint4 raw = P.hypb[(bk * P.hn_pad + h0 + t * 32 + col) * 2 + half];
             B[t] = __builtin_bit_cast(bf16x8, raw);
         }
-        __syncthreads();  // the previous item's tiles, raw records and cell list have been consumed
-        if (threadIdx.x == 0) s_ncell = 0;
-        for (int i = threadIdx.x; i < npx; i += 256) {
+        for (int i = tid; i < npx; i += 256) {
             const int p = cg * npx + i;
             float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p < tpad) q = P.rec[bk * P.cap + p];
@@ -1095,6 +1117,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             uint4* t = s_t + (i >> 5) * TILE_U4 + (i & 31) * 2;
             a_rows_exact(q, P.tau, ox, oy, rho, t[0], t[1], t[64], t[65]);
         }
+#pragma unroll
+        for (int j = 0; j < (4 * MH * 32 + 255) / 256; ++j)
+            if (tid + 256 * j < 4 * MH * 32) s_hyp[tid + 256 * j] = hreg[j];
         __syncthreads();
 
         unsigned cnt[MH];   // wrapped vote counters of the clean cells (vote8)
@@ -1158,7 +1183,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 votes = bad ? 0 : votes_of(cnt[t]);
                 mask = bad ? all_tiles : 0u;
             }
-            const int c = votes + __shfl_xor(votes, 32, 64);  // the half-waves hold different rows of the column
+            const int c = half_wave_sum(votes);  // the half-waves hold different rows of the column
             if (half == 0 && c > 0) atomicAdd(pcnt + t * 32 + colx, c);
             if (h0 + t * 32 + colx >= P.hn) mask = 0u;  // padding columns of the last slice: nobody reads their counts
             const unsigned long long bal = __ballot(mask != 0u);
@@ -1174,13 +1199,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         // ---- flagged cells, decided by the reference's arithmetic: 16 lanes per cell, one pixel row each
         const int ncell = s_ncell;
         if (ncell > 0) {
-            const int grp = threadIdx.x >> 4, q = threadIdx.x & 15;
+            int tid2 = threadIdx.x;
+            asm volatile("" : "+v"(tid2));
+            const int grp = tid2 >> 4, q = tid2 & 15;
             int ntests = 0;
             for (int e = grp; e < ncell; e += 16) {
                 const unsigned cell = s_cells[e];
                 const int hl = (int)(cell & 1023u), hf = (int)((cell >> 10) & 1u);
                 unsigned m = cell >> 11;
-                const float2 hv = P.hyp[bk * P.hn_pad + hslice + hl];
+                const float2 hv = s_hyp[hl];
                 const int row = (q >> 2) * 8 + hf * 4 + (q & 3);  // the 16 rows a lane of that half-wave holds
                 int votes = 0;
                 while (m) {
@@ -1197,7 +1224,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 if (q == 0 && votes > 0) atomicAdd(P.counts + bk * P.hn_pad + hslice + hl, votes);
             }
             if (P.flags & PVNET_F_BAND_STATS) {  // development aid: how much was re-evaluated (tools/band_stats.py)
-                if (threadIdx.x == 0) atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 4, ncell);
+                if (tid2 == 0) atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 4, ncell);
                 if (q == 0 && ntests > 0) atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 5, ntests);
             }
         }
@@ -1661,19 +1688,23 @@ inline void op_voting_grid(int tn, int vn, int hn, int* hslice, int* slices) {
 //            product; the eight further u cover the roundings of M = u g sigma, T = tau M, T +- N, the two constants
 //            Ec, Ed (2 u r |M| each), h - o, (h - o) s, tau itself and the three dropped part pairs of the bf16x3 split
 //            (0.52 u).
-// Doubled for the final safety margin -- the band is ~1e-5 of the tests at thresh 0.99, so its width costs nothing.
+// The terms are worst-case bounds (the matrix pipe's constant is twice what was measured): no further factor is applied,
+// because the band's width is what the exact mode costs -- 2e-4 of the tests lie inside it at thresh 0.99 on the noisy
+// benchmark field (tools/exact_probe.py), each flagging its cell.
 float band_constant(float thresh) {
     const double u = ldexp(1.0, -24), t = (double)thresh;
     const double tau = sqrt(1.0 - t * t) / t;
     const double k_lit = 10.0 * u * (1.0 + tau * tau) / tau * 1.001;
     const double k_fast = u * (1.0 + tau) * (1.43 * 10.0 + 8.0);
-    return (float)(2.0 * (k_lit + k_fast));
+    return (float)(k_lit + k_fast);
 }
-// cell size of the exact mode: per pixel tile when the band is wide (thresh -> 1: 1 / sin t0 grows and the threshold angle
-// moves into the noise of a real vector field, so many cells hold a test inside the band), per work item otherwise
+// cell size of the exact mode: one pixel tile (16 tests per lane) unless the threshold is so loose that hardly any test
+// falls into the band.  Measured at the benchmark shape (tools/exact_probe.py, profiles/r03_exact_probe.txt): thresh 0.9 --
+// item cells 146 us, tile cells 152 us; 0.99 -- 190 / 177 us; 0.999 -- 340 / 200 us (the threshold angle, 2.6 degrees,
+// sits inside the field's noise there: 6e-4 of the tests are re-evaluated).
 int band_fold1(int forced, float thresh) {
     if (forced == 0 || forced == 1) return forced;
-    return thresh > 0.995f ? 1 : 0;
+    return thresh > 0.95f ? 1 : 0;
 }
 
 int env_int(const char* name, int dflt) {
@@ -1786,7 +1817,7 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
         const dim3 g3(P.nseg, P.b, (P.vn + 2) / 3);
 #define PV_K2(VT)                                                                                                  \
     do {                                                                                                           \
-        if (literal) hipLaunchKernelGGL((compact_kernel<true, 3, VT>), g3, dim3(256), 0, s, P);                    \
+        if (literal || P.exact) hipLaunchKernelGGL((compact_kernel<true, 3, VT>), g3, dim3(256), 0, s, P);         \
         else if (kg == 1) hipLaunchKernelGGL((compact_kernel<false, 1, VT>), grid, dim3(256), 0, s, P);            \
         else if (kg == 9) hipLaunchKernelGGL((compact_kernel<false, 9, VT>), grid, dim3(256), 0, s, P);            \
         else hipLaunchKernelGGL((compact_kernel<false, 3, VT>), g3, dim3(256), 0, s, P);                           \
@@ -1817,7 +1848,7 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
             const int mh = P.wg_g * P.hpl / 2;
             const int npx = P.wg_s * P.chunk;
             const size_t lds = (size_t)(npx / 32) * TILE_U4 * sizeof(uint4) + (size_t)npx * sizeof(float4) +
-                               (size_t)4 * mh * 64 * sizeof(unsigned);
+                               (size_t)4 * mh * 32 * sizeof(float2) + (size_t)4 * mh * 64 * sizeof(unsigned);
             const dim3 g((unsigned)wgs), t(256);
             const bool fold1 = P.fold1 != 0;
 #define PV_EXACT(MH_)                                                                                               \

@@ -109,14 +109,27 @@ def projection_2d_error(pose_pred, pose_target, model, K, symmetric=False):
     return float(np.mean(np.linalg.norm(a - b, axis=-1)))
 
 
+# the reference's `Projector.intrinsic_matrix` (lib/utils/base_utils.py:240-250), which `Evaluator.evaluate*` index by
+# `intri_type` (evaluation_utils.py:146-149, :182-185, :204): 'blender' (the DEFAULT of all three) is fx = fy = 700,
+# c = (320, 240) -- NOT the LINEMOD camera
+INTRINSIC_MATRIX = {
+    "linemod": np.array([[572.4114, 0.0, 325.2611], [0.0, 573.57043, 242.04899], [0.0, 0.0, 1.0]]),
+    "blender": np.array([[700.0, 0.0, 320.0], [0.0, 700.0, 240.0], [0.0, 0.0, 1.0]]),
+    "pascal": np.array([[-3000.0, 0.0, 0.0], [0.0, 3000.0, 0.0], [0.0, 0.0, 1.0]]),
+}
+
+
 class Evaluator(object):
-    """evaluation_utils.py:64-226 with the dataset look-ups replaced by constructor arguments (see module docstring)."""
+    """evaluation_utils.py:64-226 with the dataset look-ups replaced by constructor arguments (see module docstring).
+    ``K`` (optional) REPLACES the whole intrinsics table: every ``intri_type`` then resolves to it -- for callers whose
+    camera is none of the reference's three; without it the table is the reference's own."""
 
     def __init__(self, models=None, diameters=None, points_3d=None, K=None):
         self.models = dict(models or {})
         self.diameters = dict(diameters or {})
         self.points_3d = dict(points_3d or {})
-        self.K = np.asarray(K if K is not None else P.LINEMOD_K, np.float64)
+        self.K = None if K is None else np.asarray(K, np.float64)
+        self.intrinsic_matrix = {k: v.copy() for k, v in INTRINSIC_MATRIX.items()}
         self.projection_2d_recorder = []
         self.add_recorder = []
         self.cm_degree_5_recorder = []
@@ -150,8 +163,17 @@ class Evaluator(object):
         self.cm_degree_5_recorder.append(tr < 5 and rot < 5)
 
     # ---- evaluate* : PnP + the metrics of one image (:136-217) ------------------------------------------------
-    def _intrinsics(self, intri_type, intri_matrix):
-        return np.asarray(intri_matrix, np.float64) if intri_type == "use_intrinsic" and intri_matrix is not None else self.K
+    def _intrinsics(self, intri_type, intri_matrix=None):
+        """the camera matrix as the reference resolves it (:146-149): the caller's matrix for 'use_intrinsic', else the
+        table entry of `intri_type` ('blender' by default); an unknown type raises, as the reference's dict look-up does"""
+        if intri_type == "use_intrinsic" and intri_matrix is not None:
+            return np.asarray(intri_matrix, np.float64)
+        if self.K is not None:
+            return self.K
+        if intri_type not in self.intrinsic_matrix:
+            raise KeyError(f"unknown intri_type {intri_type!r} (known: {sorted(self.intrinsic_matrix)} or 'use_intrinsic' "
+                           f"with intri_matrix)")
+        return self.intrinsic_matrix[intri_type]
 
     def _record(self, pose_pred, pose_targets, class_type, K, sym_projection=False):
         model, diameter = self.models[class_type], self.diameters[class_type]
@@ -191,9 +213,10 @@ class Evaluator(object):
         return pose_pred
 
     def evaluate_uncertainty_v2(self, mean_pts2d, covar, pose_targets, class_type, intri_type="blender", vote_type=None):
+        K = self._intrinsics(intri_type)  # :204: the table entry of intri_type (no 'use_intrinsic' branch here upstream)
         pose_pred = P.uncertainty_pnp_v2(np.asarray(mean_pts2d, np.float64), np.asarray(covar, np.float64),
-                                         self.points_3d[class_type], self.K)
-        self._record(pose_pred, np.asarray(pose_targets, np.float64), class_type, self.K, sym_projection=True)
+                                         self.points_3d[class_type], K)
+        self._record(pose_pred, np.asarray(pose_targets, np.float64), class_type, K, sym_projection=True)
         return pose_pred
 
     def average_precision(self, verbose=True):

@@ -34,6 +34,8 @@ def load_pnp_library() -> C.CDLL:
         lib.uncertainty_pnp.argtypes = [dp] * 6 + [C.c_int]
         lib.pvnet_pnp_refine.restype = C.c_int
         lib.pvnet_pnp_refine.argtypes = [dp] * 6 + [C.c_int, C.c_int, dp]
+        lib.pvnet_pnp_evaluate.argtypes = [dp] * 5 + [C.c_int, dp, dp]
+        lib.pvnet_pnp_evaluate.restype = C.c_int
         lib.pvnet_pnp_solve.restype = C.c_int
         lib.pvnet_pnp_solve.argtypes = [dp] * 5 + [C.c_int]
         lib.pvnet_pnp_solve_batch.restype = C.c_int
@@ -71,6 +73,26 @@ def _refine(x0, points_3d, points_2d, K, W, backend):
     return out
 
 LINEMOD_K = np.array([[572.4114, 0., 325.2611], [0., 573.57043, 242.04899], [0., 0., 1.]])  # base_utils.py:241-243
+
+
+def cost_function(points_2d, points_3d, weights_2d, camera_matrix, rt, jacobian=True):
+    """residuals [2 pn] (and their Jacobian [2 pn, 6] w.r.t. angle-axis + translation) of the native solver's cost function
+    at pose ``rt`` [6] -- ``pvnet_pnp_evaluate``: the reference's ``ReprojectionErrorArray`` (uncertainty_pnp.cpp:16-35) and
+    what its ``ceres::AutoDiffCostFunction`` derives from it.  ``weights_2d`` [pn, 3] = (wxx, wxy, wyy) or None."""
+    lib = load_pnp_library()
+    x2 = np.ascontiguousarray(points_2d, np.float64)
+    x3 = np.ascontiguousarray(points_3d, np.float64)
+    K = np.ascontiguousarray(camera_matrix, np.float64)
+    p = np.ascontiguousarray(rt, np.float64)
+    W = None if weights_2d is None else np.ascontiguousarray(weights_2d, np.float64)
+    pn = x2.shape[0]
+    r = np.empty(2 * pn)
+    J = np.empty((2 * pn, 6)) if jacobian else None
+    rc = lib.pvnet_pnp_evaluate(_dptr(x2), _dptr(x3), None if W is None else _dptr(W), _dptr(K), _dptr(p), pn, _dptr(r),
+                                None if J is None else _dptr(J))
+    if rc:
+        raise RuntimeError(f"pvnet_pnp_evaluate returned {rc}")
+    return (r, J) if jacobian else r
 
 
 def rodrigues(rvec: np.ndarray) -> np.ndarray:

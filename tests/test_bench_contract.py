@@ -21,9 +21,9 @@ def test_usable_cores_and_traffic_helpers():
     bench = importlib.import_module("bench")
     n = bench.usable_cores()
     assert 1 <= n <= (os.cpu_count() or 1)
-    t = bench.measured_traffic("score_kernel")
-    assert t is None or t > 0
-    assert bench.measured_traffic("no_such_kernel") is None
+    t, tag, name = bench.measured_traffic("score_exact_kernel")
+    assert t is None or (t > 0 and name.startswith("score_exact_kernel<"))
+    assert bench.measured_traffic("no_such_kernel")[0] is None
 
 
 def test_cpu_baseline_leg_runs_on_a_tiny_budget():
@@ -77,8 +77,22 @@ def test_gpus_must_match_world_size():
 
 def test_roofline_helpers_read_the_committed_profiles():
     bench = importlib.import_module("bench")
-    u = bench.measured_mfma_util()
+    u, tag = bench.measured_mfma_busy()
     assert u is None or 0.0 < u < 1.0
     for k in bench.PATH_KERNELS:
-        t = bench.measured_traffic(k)
-        assert t is None or t >= 0
+        t, tag, name = bench.measured_traffic(k)
+        assert t is None or (t >= 0 and name.split("<")[0] == k)  # one template instantiation, never a mix of them
+    # a profile is only quoted when it was taken from this build's kernel sources
+    tag, kernels, fresh = bench.committed_profile("_traffic.json")
+    if tag is not None and not fresh:
+        assert all(bench.measured_traffic(k)[0] is None for k in bench.PATH_KERNELS)
+    assert len(bench.source_hash()) == 16
+
+
+def test_gpu_sampler_is_harmless_without_a_gpu():
+    bench = importlib.import_module("bench")
+    import time
+    with bench.GpuSampler(0, period=0.001) as s:
+        time.sleep(0.01)
+    r = s.summary()
+    assert set(r) == {"sclk_mhz", "power_w", "source"}

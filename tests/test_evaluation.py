@@ -68,11 +68,11 @@ def test_evaluator_asymmetric_metrics_and_aggregation():
     diameter = float(np.max(np.linalg.norm(model[:, None] - model[None], axis=-1)))
     ev = E.Evaluator(models={"cat": model}, diameters={"cat": diameter}, points_3d={"cat": kp3d})
     pts2d = P.project(kp3d, pose, P.LINEMOD_K)
-    p = ev.evaluate(pts2d, pose, "cat")  # exact key-points: the pose comes back, every metric passes
+    p = ev.evaluate(pts2d, pose, "cat", intri_type="linemod")  # exact key-points: the pose comes back, every metric passes
     assert P.cm_degree_error(p, pose)[0] < 1e-3
     off = pose.copy()
     off[:, 3] += [0.0, 0.0, 0.2]  # 20 cm along the optical axis: ADD and 5cm/5deg fail, 2-D projection shrinks
-    ev.evaluate(P.project(kp3d, off, P.LINEMOD_K), pose, "cat")
+    ev.evaluate(P.project(kp3d, off, P.LINEMOD_K), pose, "cat", intri_type="linemod")
     assert ev.add_recorder == [True, False] and ev.cm_degree_5_recorder == [True, False]
     assert ev.projection_2d_recorder[0] is True or ev.projection_2d_recorder[0] == True  # noqa: E712
     assert abs(ev.add_dists[1] - 0.2) < 1e-3 and ev.add_dists[0] < 1e-4
@@ -80,9 +80,36 @@ def test_evaluator_asymmetric_metrics_and_aggregation():
     assert add == 0.5 and cm == 0.5 and proj in (0.5, 1.0)
     # the uncertainty paths run on the same recorders (isotropic covariances = plain PnP)
     cov = np.tile(np.eye(2) * 4.0, (9, 1, 1))
-    ev.evaluate_uncertainty(pts2d, cov, pose, "cat")
-    ev.evaluate_uncertainty_v2(pts2d, cov, pose, "cat")
+    ev.evaluate_uncertainty(pts2d, cov, pose, "cat", intri_type="linemod")
+    ev.evaluate_uncertainty_v2(pts2d, cov, pose, "cat", intri_type="linemod")
     assert ev.add_recorder[2:] == [True, True] and len(ev.uncertainty_pnp_cost) == 1
+
+
+def test_evaluator_resolves_intrinsics_like_the_reference():
+    """`intri_type` indexes the reference's Projector.intrinsic_matrix (base_utils.py:240-250) and its DEFAULT
+    is 'blender' (fx = fy = 700, c = (320, 240)) -- not the LINEMOD camera (evaluation_utils.py:143-149, :204)."""
+    model, kp3d, pose = _toy_object(3)
+    ev = E.Evaluator(models={"cat": model}, diameters={"cat": 0.2}, points_3d={"cat": kp3d})
+    np.testing.assert_array_equal(ev._intrinsics("blender"), [[700, 0, 320], [0, 700, 240], [0, 0, 1]])
+    np.testing.assert_allclose(ev._intrinsics("linemod"), P.LINEMOD_K)
+    assert ev._intrinsics("pascal")[0, 0] == -3000.0
+    with pytest.raises(KeyError):
+        ev._intrinsics("no_such_camera")
+    Kb = E.INTRINSIC_MATRIX["blender"]
+    for fn, extra in ((ev.evaluate, ()), ):
+        p = fn(P.project(kp3d, pose, Kb), pose, "cat")            # default type: the blender camera recovers the pose
+        assert P.cm_degree_error(p, pose)[0] < 1e-3
+        q = fn(P.project(kp3d, pose, P.LINEMOD_K), pose, "cat")   # LINEMOD key-points under the default camera do NOT
+        assert P.cm_degree_error(q, pose)[0] > 1.0
+    cov = np.tile(np.eye(2) * 4.0, (9, 1, 1))
+    p = ev.evaluate_uncertainty_v2(P.project(kp3d, pose, Kb), cov, pose, "cat")
+    assert P.cm_degree_error(p, pose)[0] < 1e-3
+    Kc = np.array([[500.0, 0, 300], [0, 510.0, 200], [0, 0, 1]])
+    p = ev.evaluate(P.project(kp3d, pose, Kc), pose, "cat", intri_type="use_intrinsic", intri_matrix=Kc)
+    assert P.cm_degree_error(p, pose)[0] < 1e-3
+    ev2 = E.Evaluator(models={"cat": model}, diameters={"cat": 0.2}, points_3d={"cat": kp3d}, K=Kc)  # constructor override
+    p = ev2.evaluate(P.project(kp3d, pose, Kc), pose, "cat")
+    assert P.cm_degree_error(p, pose)[0] < 1e-3
 
 
 # ------------------------------------------------------------------------------------------------------------ GPU
@@ -150,8 +177,8 @@ def test_add_s_and_symmetric_projection_for_a_symmetric_object():
     ev = E.Evaluator(models={"eggbox": model, "cat": model}, diameters={"eggbox": diam, "cat": diam},
                      points_3d={"eggbox": kp3d, "cat": kp3d})
     pts2d = P.project(kp3d, turned, P.LINEMOD_K)  # a detector that found the turned pose
-    ev.evaluate(pts2d, pose, "eggbox")  # symmetric class: ADD-S -> correct
-    ev.evaluate(pts2d, pose, "cat")     # ordinary class: ADD -> wrong
+    ev.evaluate(pts2d, pose, "eggbox", intri_type="linemod")  # symmetric class: ADD-S -> correct
+    ev.evaluate(pts2d, pose, "cat", intri_type="linemod")     # ordinary class: ADD -> wrong
     assert ev.add_recorder == [True, False]
 
 

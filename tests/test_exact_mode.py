@@ -117,7 +117,7 @@ def test_clean_field_and_thinned_masks(fold):
     assert float((out_e.cpu() - torch.from_numpy(kp[:3]).float()).norm(dim=2).max()) < 1e-2
     # tn0 > max_num: the thinned pixel list is the same in both modes
     _, lit, _, ex = both_modes(m, v, 128, 0.99, max_num=2000)
-    assert int(ex["tn0"][0]) > 2000 > int(ex["tn"][0]) > 1500
+    assert int(ex["tn0"][0]) > 2500 > int(ex["tn"][0]) > 1500  # thinned to ~max_num (+ < tn0 / 1024)
     assert_same_integers(lit, ex, 3)
 
 

@@ -68,6 +68,46 @@ def test_native_lm_matches_scipy_lm():
         np.testing.assert_allclose(a, b, atol=2e-6)
 
 
+def test_cost_function_and_jacobian_equal_the_references_functor():
+    """the cost function the native LM minimises is pinned to the REFERENCE'S OWN
+    `ReprojectionErrorArray::operator()` (uncertainty_pnp.cpp:16-35), compiled from the reference tree against its
+    vendored header-only ceres/jet.h + ceres/rotation.h (oracle/_ref/libpvnet_refpnp.so; the vendored libceres itself
+    cannot be linked here).  Residuals (functor on doubles) AND Jacobians (functor on ceres::Jet<double, 6>, i.e. what
+    ceres::AutoDiffCostFunction<ReprojectionErrorArray, 2, 6> at :46-47 hands to the solver) on 120 random poses, including
+    rotation angles -> 0 (the Taylor branch of ceres::AngleAxisRotatePoint, rotation.h) and -> pi, full symmetric weights."""
+    from oracle import refpnp
+    if not refpnp.available():
+        pytest.skip("oracle/_ref/libpvnet_refpnp.so not built (needs the reference tree: make -C oracle ref)")
+    rng = np.random.default_rng(17)
+    K = np.array([[572.4114, 0.0, 325.2611], [0.0, 573.57043, 242.04899], [0.0, 0.0, 1.0]])
+    angles = [0.0, 1e-12, 1e-9, 3e-8, 1e-6, 1e-4, 1e-2, np.pi - 1e-3, np.pi - 1e-7, np.pi, np.pi + 1e-4, 4.0]
+    worst_r = worst_j = 0.0
+    for trial in range(120):
+        pn = int(rng.integers(1, 12))
+        X = rng.uniform(-0.1, 0.1, size=(pn, 3))
+        th = angles[trial] if trial < len(angles) else rng.uniform(0.0, np.pi)
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        rt = np.concatenate([axis * th, [rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), rng.uniform(0.4, 2.0)]])
+        x = rng.uniform(0, 640, size=(pn, 2))
+        W = np.stack([rng.uniform(0.1, 5, pn), rng.uniform(-1, 1, pn), rng.uniform(0.1, 5, pn)], 1)  # (wxx, wxy, wyy)
+        r_ref, J_ref = refpnp.jacobian(x, X, W, K, rt)
+        np.testing.assert_allclose(refpnp.residuals(x, X, W, K, rt), r_ref, rtol=1e-14, atol=1e-12)  # Jet value part = plain evaluation
+        r, J = P.cost_function(x, X, W, K, rt)
+        sr = np.abs(r_ref).max()
+        np.testing.assert_allclose(r, r_ref, rtol=0, atol=1e-12 * max(1.0, sr))
+        sj = np.abs(J_ref).max()
+        np.testing.assert_allclose(J, J_ref, rtol=0, atol=2e-9 * max(1.0, sj))
+        worst_r = max(worst_r, np.abs(r - r_ref).max() / max(1.0, sr))
+        worst_j = max(worst_j, np.abs(J - J_ref).max() / max(1.0, sj))
+    print(f"cost function vs the reference's functor: residuals {worst_r:.1e}, Jacobians {worst_j:.1e} (relative to the largest entry)")
+    # identity weights (what pvnet_pnp_solve's first stage and `pnp` use) = the functor with (1, 0, 1)
+    r_id, J_id = P.cost_function(x, X, None, K, rt)
+    r_ref, J_ref = refpnp.jacobian(x, X, np.tile([1.0, 0.0, 1.0], (pn, 1)), K, rt)
+    np.testing.assert_allclose(r_id, r_ref, atol=1e-10)
+    np.testing.assert_allclose(J_id, J_ref, atol=2e-9 * max(1.0, np.abs(J_ref).max()))
+
+
 def test_reference_c_signature_uncertainty_pnp(demo_fixture):
     """the symbol the reference's cffi stub binds (uncertainty_pnp.cpp:61-69): void, 6 double* + int"""
     import ctypes as C

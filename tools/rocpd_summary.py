@@ -13,6 +13,25 @@ def short(name):
     return name[:90]
 
 
+def inst(name):
+    """the kernel's name WITH its template arguments ("score_exact_kernel<8, false, false>"): the json summaries are keyed
+    by instantiation, so that the literal-mode instantiations a profiled run also launches are never mixed into the
+    timed ones"""
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\s*\[clone[^\]]*\]\s*$", "", name)
+    name = re.sub(r"\(.*\)$", "", name).strip()
+    return name if re.match(r"\w+_kernel(<.*>)?$", name) else None
+
+
+def source_hash():
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    return bench.source_hash()
+
+
 def kernel_stats(db):
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
@@ -52,15 +71,18 @@ def main(src, dst):
     for kind in ("fetch", "write"):
         for db in glob.glob(os.path.join(src, f"pmc_{kind}", "*.db")):
             cur = sqlite3.connect(db).cursor()
-            for k, v in cur.execute("select kernel_name, avg(value) from counters_collection where counter_name=? "
-                                    "group by kernel_name", (kind.upper() + "_SIZE",)):
-                m = re.search(r"(\w+_kernel)", k)
-                if m:
-                    traffic.setdefault(m.group(1), {})[kind + "_kb"] = v
+            for k, v, n in cur.execute("select kernel_name, avg(value), count(*) from counters_collection where "
+                                       "counter_name=? group by kernel_name", (kind.upper() + "_SIZE",)):
+                name = inst(k)
+                if name:
+                    traffic.setdefault(name, {})[kind + "_kb"] = v
+                    traffic[name]["n"] = n
     if traffic:
         import json
         with open(dst + "_traffic.json", "w") as f:
-            json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), average per dispatch, KB",
+            json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), average per dispatch, KB; keyed by "
+                                 "template instantiation, n = dispatches",
+                       "source_hash": source_hash(),
                        "note": "gfx950 FETCH_SIZE counts wide coalesced reads at 1/2 (MI355X_MICROARCH.md, HBM): "
                                "bench.py doubles fetch_kb",
                        "kernels": traffic}, f, indent=1)
@@ -68,16 +90,19 @@ def main(src, dst):
     counters = {}
     for db in sorted(glob.glob(os.path.join(src, "pmc*", "*.db"))):
         cur = sqlite3.connect(db).cursor()
-        for k, c, v, d in cur.execute("select kernel_name, counter_name, avg(value), avg(duration) from "
-                                      "counters_collection group by kernel_name, counter_name"):
-            m = re.search(r"(\w+_kernel)", k)
-            if m:
-                counters.setdefault(m.group(1), {})[c] = v
-                counters[m.group(1)].setdefault("avg_duration_us", {})[c] = d / 1e3
+        for k, c, v, d, n in cur.execute("select kernel_name, counter_name, avg(value), avg(duration), count(*) from "
+                                         "counters_collection group by kernel_name, counter_name"):
+            name = inst(k)
+            if name:
+                counters.setdefault(name, {})[c] = v
+                counters[name].setdefault("avg_duration_us", {})[c] = d / 1e3
+                counters[name]["n"] = n
     if counters:
         import json
         with open(dst + "_pmc.json", "w") as f:
-            json.dump({"source": "rocprofv3 --pmc passes (own runs, --kernel-trace only), average per dispatch",
+            json.dump({"source": "rocprofv3 --pmc passes (own runs, --kernel-trace only), average per dispatch; keyed by template "
+                                 "instantiation, n = dispatches",
+                       "source_hash": source_hash(),
                        "note": "SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the chip's SIMDs; GRBM_GUI_ACTIVE is "
                                "summed over the 8 XCDs: MfmaUtil = MFMA_BUSY / (1024 SIMDs x GUI_ACTIVE / 8)",
                        "kernels": counters}, f, indent=1)

@@ -98,6 +98,181 @@ __device__ __forceinline__ void vote8i(unsigned& acc, float d0, float c0, float 
           "v"(d6), "v"(c6), "v"(d7), "v"(c7));
 }
 
+
+// ---- a/b formulation (product: vote8ab): a = dt - cr, b = dt + cr; vote = clamp(min(a, b)); band = min over |a|, |b|
+#define AB_ARGS float a0, float b0, float a1, float b1, float a2, float b2, float a3, float b3, float a4, float b4, float a5, \
+                float b5, float a6, float b6, float a7, float b7
+#define AB_IN "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), \
+              "v"(a6), "v"(b6), "v"(a7), "v"(b7)
+// EPI 3: the product's epilogue, one min3 chain
+__device__ __forceinline__ void ab_min3_1chain(unsigned& acc, float& dm, AB_ARGS) {
+    float t0, t1, t2;
+    asm volatile(
+        "v_min_f32_e64 %2, %5, %6 clamp\n"
+        "v_min_f32_e64 %3, %7, %8 clamp\n"
+        "v_min3_f32 %1, %1, |%5|, |%6|\n"
+        "v_min_f32_e64 %4, %9, %10 clamp\n"
+        "v_min3_f32 %1, %1, |%7|, |%8|\n"
+        "v_add3_u32 %0, %2, %3, %0\n"
+        "v_min_f32_e64 %2, %11, %12 clamp\n"
+        "v_min3_f32 %1, %1, |%9|, |%10|\n"
+        "v_min_f32_e64 %3, %13, %14 clamp\n"
+        "v_min3_f32 %1, %1, |%11|, |%12|\n"
+        "v_add3_u32 %0, %4, %2, %0\n"
+        "v_min_f32_e64 %4, %15, %16 clamp\n"
+        "v_min3_f32 %1, %1, |%13|, |%14|\n"
+        "v_min_f32_e64 %2, %17, %18 clamp\n"
+        "v_min3_f32 %1, %1, |%15|, |%16|\n"
+        "v_add3_u32 %0, %3, %4, %0\n"
+        "v_min_f32_e64 %3, %19, %20 clamp\n"
+        "v_min3_f32 %1, %1, |%17|, |%18|\n"
+        "v_min3_f32 %1, %1, |%19|, |%20|\n"
+        "v_add3_u32 %0, %2, %3, %0\n"
+        : "+v"(acc), "+v"(dm), "=&v"(t0), "=&v"(t1), "=&v"(t2)
+        : AB_IN);
+}
+// EPI 4: four independent min3 chains
+__device__ __forceinline__ void ab_min3_4chain(unsigned& acc, float& d0, float& d1, float& d2, float& d3, AB_ARGS) {
+    float t0, t1, t2;
+    asm volatile(
+        "v_min_f32_e64 %5, %8, %9 clamp\n"
+        "v_min_f32_e64 %6, %10, %11 clamp\n"
+        "v_min3_f32 %1, %1, |%8|, |%9|\n"
+        "v_min_f32_e64 %7, %12, %13 clamp\n"
+        "v_min3_f32 %2, %2, |%10|, |%11|\n"
+        "v_add3_u32 %0, %5, %6, %0\n"
+        "v_min_f32_e64 %5, %14, %15 clamp\n"
+        "v_min3_f32 %3, %3, |%12|, |%13|\n"
+        "v_min_f32_e64 %6, %16, %17 clamp\n"
+        "v_min3_f32 %4, %4, |%14|, |%15|\n"
+        "v_add3_u32 %0, %7, %5, %0\n"
+        "v_min_f32_e64 %7, %18, %19 clamp\n"
+        "v_min3_f32 %1, %1, |%16|, |%17|\n"
+        "v_min_f32_e64 %5, %20, %21 clamp\n"
+        "v_min3_f32 %2, %2, |%18|, |%19|\n"
+        "v_add3_u32 %0, %6, %7, %0\n"
+        "v_min_f32_e64 %6, %22, %23 clamp\n"
+        "v_min3_f32 %3, %3, |%20|, |%21|\n"
+        "v_min3_f32 %4, %4, |%22|, |%23|\n"
+        "v_add3_u32 %0, %5, %6, %0\n"
+        : "+v"(acc), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "=&v"(t0), "=&v"(t1), "=&v"(t2)
+        : AB_IN);
+}
+// EPI 5: two-input minima instead of min3 (two chains): 3.5 operations per test
+__device__ __forceinline__ void ab_min2(unsigned& acc, float& d0, float& d1, AB_ARGS) {
+    float t0, t1, t2;
+    asm volatile(
+        "v_min_f32_e64 %3, %6, %7 clamp\n"
+        "v_min_f32_e64 %4, %8, %9 clamp\n"
+        "v_min_f32_e64 %1, %1, |%6|\n"
+        "v_min_f32_e64 %2, %2, |%7|\n"
+        "v_min_f32_e64 %1, %1, |%8|\n"
+        "v_min_f32_e64 %2, %2, |%9|\n"
+        "v_add3_u32 %0, %3, %4, %0\n"
+        "v_min_f32_e64 %3, %10, %11 clamp\n"
+        "v_min_f32_e64 %4, %12, %13 clamp\n"
+        "v_min_f32_e64 %1, %1, |%10|\n"
+        "v_min_f32_e64 %2, %2, |%11|\n"
+        "v_min_f32_e64 %1, %1, |%12|\n"
+        "v_min_f32_e64 %2, %2, |%13|\n"
+        "v_add3_u32 %0, %3, %4, %0\n"
+        "v_min_f32_e64 %3, %14, %15 clamp\n"
+        "v_min_f32_e64 %4, %16, %17 clamp\n"
+        "v_min_f32_e64 %1, %1, |%14|\n"
+        "v_min_f32_e64 %2, %2, |%15|\n"
+        "v_min_f32_e64 %1, %1, |%16|\n"
+        "v_min_f32_e64 %2, %2, |%17|\n"
+        "v_add3_u32 %0, %3, %4, %0\n"
+        "v_min_f32_e64 %3, %18, %19 clamp\n"
+        "v_min_f32_e64 %4, %20, %21 clamp\n"
+        "v_min_f32_e64 %1, %1, |%18|\n"
+        "v_min_f32_e64 %2, %2, |%19|\n"
+        "v_min_f32_e64 %1, %1, |%20|\n"
+        "v_min_f32_e64 %2, %2, |%21|\n"
+        "v_add3_u32 %0, %3, %4, %0\n"
+        : "+v"(acc), "+v"(d0), "+v"(d1), "=&v"(t0), "=&v"(t1), "=&v"(t2)
+        : AB_IN);
+}
+// EPI 6: u = clamp(min(|a|, |b|)) (1.0 unless a test is near the band), two of them per v_add3_u32: 3 operations per test
+__device__ __forceinline__ void ab_uclamp(unsigned& acc, unsigned& uacc, AB_ARGS) {
+    float t0, t1, t2, t3;
+    asm volatile(
+        "v_min_f32_e64 %2, %6, %7 clamp\n"
+        "v_min_f32_e64 %3, %8, %9 clamp\n"
+        "v_min_f32_e64 %4, |%6|, |%7| clamp\n"
+        "v_min_f32_e64 %5, |%8|, |%9| clamp\n"
+        "v_add3_u32 %0, %2, %3, %0\n"
+        "v_min_f32_e64 %2, %10, %11 clamp\n"
+        "v_min_f32_e64 %3, %12, %13 clamp\n"
+        "v_add3_u32 %1, %4, %5, %1\n"
+        "v_min_f32_e64 %4, |%10|, |%11| clamp\n"
+        "v_min_f32_e64 %5, |%12|, |%13| clamp\n"
+        "v_add3_u32 %0, %2, %3, %0\n"
+        "v_min_f32_e64 %2, %14, %15 clamp\n"
+        "v_min_f32_e64 %3, %16, %17 clamp\n"
+        "v_add3_u32 %1, %4, %5, %1\n"
+        "v_min_f32_e64 %4, |%14|, |%15| clamp\n"
+        "v_min_f32_e64 %5, |%16|, |%17| clamp\n"
+        "v_add3_u32 %0, %2, %3, %0\n"
+        "v_min_f32_e64 %2, %18, %19 clamp\n"
+        "v_min_f32_e64 %3, %20, %21 clamp\n"
+        "v_add3_u32 %1, %4, %5, %1\n"
+        "v_min_f32_e64 %4, |%18|, |%19| clamp\n"
+        "v_min_f32_e64 %5, |%20|, |%21| clamp\n"
+        "v_add3_u32 %0, %2, %3, %0\n"
+        "v_add3_u32 %1, %4, %5, %1\n"
+        : "+v"(acc), "+v"(uacc), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : AB_IN);
+}
+// EPI 7: the vote alone in the a/b form (no band): 1.5 operations per test, as EPI 0
+__device__ __forceinline__ void ab_vote_only(unsigned& acc, AB_ARGS) {
+    float t0, t1, t2, t3;
+    asm volatile(
+        "v_min_f32_e64 %1, %5, %6 clamp\n"
+        "v_min_f32_e64 %2, %7, %8 clamp\n"
+        "v_min_f32_e64 %3, %9, %10 clamp\n"
+        "v_min_f32_e64 %4, %11, %12 clamp\n"
+        "v_add3_u32 %0, %1, %2, %0\n"
+        "v_min_f32_e64 %1, %13, %14 clamp\n"
+        "v_min_f32_e64 %2, %15, %16 clamp\n"
+        "v_add3_u32 %0, %3, %4, %0\n"
+        "v_min_f32_e64 %3, %17, %18 clamp\n"
+        "v_min_f32_e64 %4, %19, %20 clamp\n"
+        "v_add3_u32 %0, %1, %2, %0\n"
+        "v_add3_u32 %0, %3, %4, %0\n"
+        : "+v"(acc), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : AB_IN);
+}
+// EPI 8: min3 WITHOUT the |.| modifiers (is it the modifiers or the instruction?)
+__device__ __forceinline__ void ab_min3_noabs(unsigned& acc, float& d0, float& d1, float& d2, float& d3, AB_ARGS) {
+    float t0, t1, t2;
+    asm volatile(
+        "v_min_f32_e64 %5, %8, %9 clamp\n"
+        "v_min_f32_e64 %6, %10, %11 clamp\n"
+        "v_min3_f32 %1, %1, %8, %9\n"
+        "v_min_f32_e64 %7, %12, %13 clamp\n"
+        "v_min3_f32 %2, %2, %10, %11\n"
+        "v_add3_u32 %0, %5, %6, %0\n"
+        "v_min_f32_e64 %5, %14, %15 clamp\n"
+        "v_min3_f32 %3, %3, %12, %13\n"
+        "v_min_f32_e64 %6, %16, %17 clamp\n"
+        "v_min3_f32 %4, %4, %14, %15\n"
+        "v_add3_u32 %0, %7, %5, %0\n"
+        "v_min_f32_e64 %7, %18, %19 clamp\n"
+        "v_min3_f32 %1, %1, %16, %17\n"
+        "v_min_f32_e64 %5, %20, %21 clamp\n"
+        "v_min3_f32 %2, %2, %18, %19\n"
+        "v_add3_u32 %0, %6, %7, %0\n"
+        "v_min_f32_e64 %6, %22, %23 clamp\n"
+        "v_min3_f32 %3, %3, %20, %21\n"
+        "v_min3_f32 %4, %4, %22, %23\n"
+        "v_add3_u32 %0, %5, %6, %0\n"
+        : "+v"(acc), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "=&v"(t0), "=&v"(t1), "=&v"(t2)
+        : AB_IN);
+}
+#define AB_HALF(o) d[o + 0], cr[o + 0], d[o + 1], cr[o + 1], d[o + 2], cr[o + 2], d[o + 3], cr[o + 3], d[o + 4], cr[o + 4], \
+                   d[o + 5], cr[o + 5], d[o + 6], cr[o + 6], d[o + 7], cr[o + 7]
+
 __global__ void k_semantics(const float* __restrict__ d, const float* __restrict__ c, unsigned* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float dv[8], cv[8];
@@ -147,6 +322,7 @@ __global__ __launch_bounds__(256) void k_pipe(const u16* __restrict__ Bsrc, cons
     for (int i = threadIdx.x; i < ntiles * TILE_BYTES / 2; i += 256) lds[i] = Asrc[i];
     bf16x8 B[MH];
     unsigned s1[MH], s2[MH];
+    float f0[MH], f1 = 3e38f, f2 = 3e38f, f3 = 3e38f;
 #pragma unroll
     for (int t = 0; t < MH; ++t) {
         const int j = (wave * MH + t) * 32 + (lane & 31);
@@ -154,6 +330,7 @@ __global__ __launch_bounds__(256) void k_pipe(const u16* __restrict__ Bsrc, cons
         for (int k = 0; k < 8; ++k) B[t][k] = __builtin_bit_cast(__bf16, Bsrc[j * 16 + half * 8 + k]);
         s1[t] = 0u;
         s2[t] = 0u;
+        f0[t] = 3e38f;
     }
     __syncthreads();
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -173,13 +350,25 @@ __global__ __launch_bounds__(256) void k_pipe(const u16* __restrict__ Bsrc, cons
                 __builtin_amdgcn_sched_barrier(0);
                 if (EPI == 0) vote8i(s1[t], d[0], cr[0], d[1], cr[1], d[2], cr[2], d[3], cr[3], d[4], cr[4], d[5], cr[5], d[6], cr[6], d[7], cr[7]);
                 else if (EPI == 1) vote8x(s1[t], s2[t], sel, ones8, d[0], cr[0], d[1], cr[1], d[2], cr[2], d[3], cr[3], d[4], cr[4], d[5], cr[5], d[6], cr[6], d[7], cr[7]);
-                else vote8y(s1[t], s2[t], ones16, d[0], cr[0], d[1], cr[1], d[2], cr[2], d[3], cr[3], d[4], cr[4], d[5], cr[5], d[6], cr[6], d[7], cr[7]);
+                else if (EPI == 2) vote8y(s1[t], s2[t], ones16, d[0], cr[0], d[1], cr[1], d[2], cr[2], d[3], cr[3], d[4], cr[4], d[5], cr[5], d[6], cr[6], d[7], cr[7]);
+                else if (EPI == 3) ab_min3_1chain(s1[t], f0[t], AB_HALF(0));
+                else if (EPI == 4) ab_min3_4chain(s1[t], f0[t], f1, f2, f3, AB_HALF(0));
+                else if (EPI == 5) ab_min2(s1[t], f0[t], f1, AB_HALF(0));
+                else if (EPI == 6) ab_uclamp(s1[t], s2[t], AB_HALF(0));
+                else if (EPI == 7) ab_vote_only(s1[t], AB_HALF(0));
+                else ab_min3_noabs(s1[t], f0[t], f1, f2, f3, AB_HALF(0));
                 __builtin_amdgcn_sched_barrier(0);
                 const f32x16 d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Ad : Nd, B[(t + 1) % MH], zero, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (EPI == 0) vote8i(s1[t], d[8], cr[8], d[9], cr[9], d[10], cr[10], d[11], cr[11], d[12], cr[12], d[13], cr[13], d[14], cr[14], d[15], cr[15]);
                 else if (EPI == 1) vote8x(s1[t], s2[t], sel, ones8, d[8], cr[8], d[9], cr[9], d[10], cr[10], d[11], cr[11], d[12], cr[12], d[13], cr[13], d[14], cr[14], d[15], cr[15]);
-                else vote8y(s1[t], s2[t], ones16, d[8], cr[8], d[9], cr[9], d[10], cr[10], d[11], cr[11], d[12], cr[12], d[13], cr[13], d[14], cr[14], d[15], cr[15]);
+                else if (EPI == 2) vote8y(s1[t], s2[t], ones16, d[8], cr[8], d[9], cr[9], d[10], cr[10], d[11], cr[11], d[12], cr[12], d[13], cr[13], d[14], cr[14], d[15], cr[15]);
+                else if (EPI == 3) ab_min3_1chain(s1[t], f0[t], AB_HALF(8));
+                else if (EPI == 4) ab_min3_4chain(s1[t], f0[t], f1, f2, f3, AB_HALF(8));
+                else if (EPI == 5) ab_min2(s1[t], f0[t], f1, AB_HALF(8));
+                else if (EPI == 6) ab_uclamp(s1[t], s2[t], AB_HALF(8));
+                else if (EPI == 7) ab_vote_only(s1[t], AB_HALF(8));
+                else ab_min3_noabs(s1[t], f0[t], f1, f2, f3, AB_HALF(8));
                 __builtin_amdgcn_sched_barrier(0);
                 cr = cr2;
                 d = d2;
@@ -190,7 +379,8 @@ __global__ __launch_bounds__(256) void k_pipe(const u16* __restrict__ Bsrc, cons
     }
 #pragma unroll
     for (int t = 0; t < MH; ++t)
-        counts[(((size_t)blockIdx.x * 4 + wave) * MH + t) * 64 + lane] = s1[t] ^ s2[t];
+        counts[(((size_t)blockIdx.x * 4 + wave) * MH + t) * 64 + lane] =
+            s1[t] ^ s2[t] ^ __builtin_bit_cast(unsigned, f0[t]) ^ __builtin_bit_cast(unsigned, f1 + f2 + f3);
 }
 
 static float h2f(unsigned short h) { _Float16 x = __builtin_bit_cast(_Float16, h); return (float)x; }
@@ -297,14 +487,14 @@ int main() {
         hipMemcpy(dA, As.data(), As.size() * 2, hipMemcpyHostToDevice);
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
-        for (int wpc = 2; wpc <= 4; ++wpc)
-            for (int epi = 0; epi < 3; ++epi) {
+        for (int wpc = 3; wpc <= 3; ++wpc)
+            for (int epi = 0; epi < 9; ++epi) {
                 const dim3 g(cus * wpc), b(256);
                 const int reps = 64;
                 auto launch = [&] {
-                    if (epi == 0) hipLaunchKernelGGL((k_pipe<MH, 0>), g, b, ntiles * TILE_BYTES, 0, dB, dA, dc, ntiles, reps);
-                    else if (epi == 1) hipLaunchKernelGGL((k_pipe<MH, 1>), g, b, ntiles * TILE_BYTES, 0, dB, dA, dc, ntiles, reps);
-                    else hipLaunchKernelGGL((k_pipe<MH, 2>), g, b, ntiles * TILE_BYTES, 0, dB, dA, dc, ntiles, reps);
+#define LAUNCH(E) case E: hipLaunchKernelGGL((k_pipe<MH, E>), g, b, ntiles * TILE_BYTES, 0, dB, dA, dc, ntiles, reps); break;
+                    switch (epi) { LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) }
+#undef LAUNCH
                 };
                 launch();
                 hipDeviceSynchronize();
@@ -320,7 +510,11 @@ int main() {
                 }
                 const double tests = (double)g.x * 4 * MH * 32 * ntiles * 32 * reps;
                 printf("workgroups/CU %d  MH=%d  %s: %8.3f ms  %7.2f T tests/s\n", wpc, MH,
-                       epi == 0 ? "clamp + add3            (1.5  op/test)" : epi == 1 ? "mix + perm + dot4 moments (1.75 op/test)" : "mix + dot2 moments        (2.0  op/test)",
+                       epi == 0 ? "clamp + add3              (1.5  op/test)" : epi == 1 ? "mix + perm + dot4 moments (1.75 op/test)" :
+                       epi == 2 ? "mix + dot2 moments        (2.0  op/test)" : epi == 3 ? "a/b: min-clamp, min3 x1 chain, add3 (2.5)" :
+                       epi == 4 ? "a/b: min-clamp, min3 x4 chains, add3 (2.5)" : epi == 5 ? "a/b: min-clamp, 2 x min |.|, add3  (3.5)" :
+                       epi == 6 ? "a/b: min-clamp, min|.|-clamp, 2 add3 (3.0)" : epi == 7 ? "a/b: min-clamp + add3 only        (1.5)" :
+                                  "a/b: min3 without |.|, 4 chains    (2.5)",
                        best, tests / best / 1e9);
             }
     }
