@@ -91,7 +91,8 @@ typedef struct PvnetVoteLayout {
                                work item holds wg_g*64*hpl hypotheses = 4 waves x (wg_g*hpl/2) MFMA tiles of 32 */
     int32_t hgroups;        /* hypothesis groups per key-point = ceil(hn / (64*hpl)) rounded up to wg_g     */
     int32_t hn_pad;         /* hgroups * 64 * hpl                                                           */
-    size_t off_ctrl;        /* int32 [b][8]: tn0, tn, status, item_base, nchunks, -, -, -  ; then [8] global */
+    size_t off_ctrl;        /* int32 [b][8]: tn0, tn, status, item_base, nchunks, origin x, origin y, -  ; then [8] global: total items, -,
+                               (2,3) stage-timer ticks, (4,5) band statistics (PVNET_F_BAND_STATS), (6) layout fingerprint */
     size_t off_bits;        /* uint64 [b][words]           foreground bit mask (as the mask has it: before thinning) */
     size_t off_pix;         /* int32  [b][cap]             linear pixel index y*w+x of compacted pixel t    */
     size_t off_rec;         /* float4 [b][vn][cap]         record (x, y, ux, uy): pixel and its RAW direction for the

@@ -91,7 +91,7 @@ def subsample_threshold(max_num: int, tn0: int) -> int:
     tn0 > max_num; here the probability is rounded UP to the next multiple of 1/1024 -- k = ceil(1024 max_num / tn0),
     threshold = k << 22, i.e. keep <=> (rng >> 22) < k -- so that the mask kernel can count, per 4096-pixel segment, how
     many pixels every one of the 1024 possible decisions keeps (a cumulative histogram of the top ten bits) before tn0 is
-    known, and compaction needs no separate thinning launch.  Expected kept pixels: tn0 k / 256 in [max_num,
+    known, and compaction needs no separate thinning launch.  Expected kept pixels: tn0 k / 1024 in [max_num,
     max_num + tn0 / 1024)."""
     if tn0 <= max_num:
         return 1 << 32

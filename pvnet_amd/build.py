@@ -108,6 +108,36 @@ def build_ext(force: bool = False, verbose: bool = False):
     return out
 
 
+# the compaction-flake canary (tests/test_flake_canary.py): the stand-alone reproducer of round 2's wrong-record flake, once as
+# it failed (VGPR allocation used to its last granule) and once with the spare granule every kernel of the library keeps
+CANARY_SRC = os.path.join(ROOT, "tools", "experiments", "k2_flake", "k2_repro.hip")
+CANARY_BINS = {"tight": os.path.join(ROOT, "tools", "experiments", "k2_flake", "k2_repro_tight.bin"),
+               "spare": os.path.join(ROOT, "tools", "experiments", "k2_flake", "k2_repro_spare.bin")}
+
+
+def build_canary(force: bool = False, verbose: bool = False):
+    for kind, out in CANARY_BINS.items():
+        if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(CANARY_SRC):
+            continue
+        cmd = [hipcc_path(), "-O3", f"--offload-arch={ARCH}", "-w", CANARY_SRC, "-o", out] + (["-DV_SPARE"] if kind == "spare" else [])
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return CANARY_BINS
+
+
+def check_resources() -> None:
+    """the spare-VGPR-granule rule is enforced AT BUILD TIME, not only by a CPU test that needs hipcc: a library
+    whose kernels use their allocation to the last granule is not produced (tools/check_kernel_resources.py; the same for
+    the hand-placed MFMA epilogues, tools/check_mfma_hazard.py)."""
+    for tool in ("check_kernel_resources.py", "check_mfma_hazard.py"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)], capture_output=True, text=True)
+        if r.returncode != 0:
+            if os.path.exists(LIB):
+                os.remove(LIB)
+            raise RuntimeError(f"pvnet_amd.build: tools/{tool} rejects this build (library removed):\n" + r.stdout[-3000:] + r.stderr[-1000:])
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     build_pnp(force, verbose)
     if force or not up_to_date():
@@ -115,7 +145,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        check_resources()
     build_ext(force, verbose)
+    build_canary(force, verbose)
     return LIB
 
 

@@ -10,8 +10,8 @@
 //
 // Stages (one launch each, all images of the batch at once):
 //   K1 mask_bits      mask (any int dtype / f32, any strides) -> 1 bit per pixel + per-segment counts  [HBM read]
-//                     + per segment the cumulative histogram of the thinning decisions (Bernoulli(k / 256) with
-//                     k = ceil(256 max_num / tn0), decided on the device once tn0 is known)
+//                     + per segment the cumulative histogram of the thinning decisions (Bernoulli(k / 1024) with
+//                     k = ceil(1024 max_num / tn0), decided on the device once tn0 is known)
 //   K2 compact        thins its own segment when tn0 > max_num, then order-preserving (raster) compaction: segment counts + wave scan of word popcounts give
 //                     every kept pixel its slot; one thread per kept pixel gathers its vn direction vectors
 //                     straight from the strided field (planar in practice -> consecutive lanes read
@@ -20,15 +20,19 @@
 //   K3 hypotheses     one thread per (image, kp, h): two pixel draws (counter RNG or caller idxs), 2x2 solve in
 //                     the reference's float32 order; also writes each hypothesis as a bf16x3 MFMA operand column and
 //                     zeroes its inlier count; one extra block per image plans the scoring work items
-//   K4 score          DOMINANT.  Fast mode (score_mfma_kernel): the vote is two 3-term fp32 dot products and a
-//                     compare; every operand is split into three bf16 parts, so each dot product is ONE
-//                     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (fp32-equivalent accuracy, measured), and
-//                     the lane that owns the hypothesis counts its 16 results as t = clamp(dt - |cr|) (the
-//                     per-record 2^60 scaling makes the clamp an exact 1.0f / 0) summed two at a time by a wrapping
-//                     v_add3_u32: 2 MFMAs + 1.5 VALU ops per test (vote8).  Records are expanded and staged in
-//                     LDS once per work item.
+//   K4 score          DOMINANT.  The vote is two 3-term fp32 dot products and a compare; every operand is split into
+//                     three bf16 parts, so each dot product is ONE v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+//                     EXACT mode (default, score_exact_kernel): the two MFMAs return a = dt - cr and b = dt + cr in units of
+//                     the float32 rounding band of the reference's test; the lane that owns the hypothesis takes
+//                     t = clamp(min(a, b)) (the vote, exactly 1.0f / 0 outside the band), sums two t's per wrapping
+//                     v_add3_u32 and keeps min |a|, |b| (v_min3_f32): 2 MFMAs + 2.5 VALU ops per test (vote8ab); cells
+//                     that hold a test inside the band are re-evaluated with the reference's own arithmetic
+//                     (inlier_literal) from the raw records, so every inlier count EQUALS the reference kernel's.
+//                     APPROX mode (PVNET_F_APPROX, score_mfma_kernel): t = clamp(dt - |cr|) on 2^60-scaled records,
+//                     2 MFMAs + 1.5 VALU ops per test (vote8), no re-evaluation: counts within a few votes.
+//                     Records are expanded and staged in LDS once per work item.
 //                     Literal mode (score_kernel<HPL,true>): "lane owns hypotheses" on the VALU in the
-//                     reference's float32 operation order, bit-exact with the reference's kernels.
+//                     reference's float32 operation order for every pair, bit-exact with the reference's kernels.
 //                     Work items go to a persistent grid XCD by XCD (one contiguous eighth of the list per XCD: the
 //                     operands of an (image, key-point) pass through one L2); counts are added into
 //                     counts[b][vn][hn] with integer atomics (zeroed by K3; order-independent, deterministic).
@@ -99,6 +103,7 @@ struct VoteParams {
     int b, h, w, vn, hn, npix, words, cap, chunk, max_chunks, hpl, hgroups, hn_pad, wg_g, wg_s, mode, score_xcd, atomic_counts;
     float thresh, tau;
     float kband;   // exact mode: half-width of the rounding band as a fraction of |d| |u| (band_constant())
+    int layout_fp; // fingerprint of the workspace layout this call was planned with (layout_fingerprint()), kept in ctrl
     int exact;     // 1: matrix-pipe scoring + literal re-evaluation of the cells that hold a pair inside the band
     int fold1;     // exact mode: 1 = a cell is one pixel tile (16 tests per lane), 0 = the whole work item (band_fold1())
     int min_num, max_num;
@@ -673,6 +678,7 @@ __device__ __forceinline__ void plan_image(const VoteParams& P, int bi) {
         if (!nch) P.ctrl[bi * CTRL_STRIDE + C_STATUS] |= PVNET_S_SKIPPED;
         if (bi == P.b - 1) {
             P.ctrl[P.b * CTRL_STRIDE] = base + n;  // total number of work items
+            P.ctrl[P.b * CTRL_STRIDE + 6] = P.layout_fp;  // which layout the offsets of this workspace follow (epilogues check)
             P.ctrl[P.b * CTRL_STRIDE + 4] = 0;     // exact mode, PVNET_F_BAND_STATS: flagged cells / literal tests
             P.ctrl[P.b * CTRL_STRIDE + 5] = 0;
         }
@@ -1060,11 +1066,12 @@ __device__ __forceinline__ void vote8ab(unsigned& acc, float& dm, float a0, floa
 }
 constexpr float BAND_CLEAN = 1.0f;     // a cell whose minimum |a'|, |b'| reaches this holds no test inside the band
 
-// FOLD1 = false: one cell per (lane, hypothesis tile) and work item -- the minimum runs over all the item's pixel tiles
-//                (cheapest epilogue; right when flagged cells are very rare: loose thresholds, band_fold1());
-// FOLD1 = true:  one cell per (lane, hypothesis tile, PIXEL tile) -- the test is made after every step, so a flagged cell
-//                costs 16 literal tests instead of 16 * tiles (right when the threshold sits inside the field's noise).
-template <int MH, bool FOLD1, bool TIMED>
+// FOLD = 0: one cell per (lane, hypothesis tile) and work item -- the minimum runs over all the item's pixel tiles
+//           (cheapest epilogue; right when flagged cells are very rare: loose thresholds, band_fold());
+// FOLD = F: one cell per (lane, hypothesis tile, F consecutive PIXEL tiles) -- the test is made after every F-th tile (five
+//           more VALU operations each time), and a flagged cell costs 16 F literal tests instead of 16 * tiles.  F = 1 is
+//           built; F = 2 measured no better on paper and keeps 17 more VGPRs live (the spare-granule rule fails).
+template <int MH, int FOLD, bool TIMED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void score_exact_kernel(VoteParams P) {
     if (MH == 8) PVNET_SPARE_VGPRS(167); else if (MH == 4) PVNET_SPARE_VGPRS(143); else PVNET_SPARE_VGPRS(111);
     unsigned long long* __restrict__ stamps = reinterpret_cast<unsigned long long*>(P.pix);
@@ -1123,11 +1130,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         __syncthreads();
 
         unsigned cnt[MH];   // wrapped vote counters of the clean cells (vote8)
-        float dmn[MH];      // FOLD1: bit mask of flagged pixel tiles (as an integer); else: min |a'|, |b'| of the cell so far
+        float dmn[MH];      // min |a'|, |b'| of the open cell so far
+        unsigned acc[MH];   // FOLD: wrapped votes of the open cell
+        // FOLD: the low 16 bits of cnt[t] (always zero in a wrapped vote counter: multiples of 0x3F800000) carry the flags:
+        // bit g set = the g-th group of FOLD pixel tiles holds a test inside the band
 #pragma unroll
         for (int t = 0; t < MH; ++t) {
-            cnt[t] = 0u;
-            dmn[t] = FOLD1 ? 0.f : 3.0e38f;
+            cnt[t] = acc[t] = 0u;
+            dmn[t] = 3.0e38f;
         }
         bf16x8 Aa = __builtin_bit_cast(bf16x8, lbase[0]), Ab = __builtin_bit_cast(bf16x8, lbase[64]);
         f32x16 va = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aa, B[0], zero, 0, 0, 0);
@@ -1138,26 +1148,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             const int nt = tile + 1 < nti ? tile + 1 : tile;
             const bf16x8 Na = __builtin_bit_cast(bf16x8, lbase[nt * TILE_U4]);
             const bf16x8 Nb = __builtin_bit_cast(bf16x8, lbase[nt * TILE_U4 + 64]);
+            const bool close = FOLD && ((tile + 1) % (FOLD ? FOLD : 1) == 0 || tile + 1 == nti);  // (wave-uniform)
 #pragma unroll
             for (int t = 0; t < MH; ++t) {
-                unsigned acc = FOLD1 ? 0u : cnt[t];
-                float d = FOLD1 ? 3.0e38f : dmn[t];
                 const f32x16 va2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Aa : Na, B[(t + 1) % MH], zero, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                vote8ab(acc, d, va[0], vb[0], va[1], vb[1], va[2], vb[2], va[3], vb[3], va[4], vb[4], va[5], vb[5],
+                vote8ab(FOLD ? acc[t] : cnt[t], dmn[t], va[0], vb[0], va[1], vb[1], va[2], vb[2], va[3], vb[3], va[4], vb[4], va[5], vb[5],
                         va[6], vb[6], va[7], vb[7]);
                 __builtin_amdgcn_sched_barrier(0);
                 const f32x16 vb2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Ab : Nb, B[(t + 1) % MH], zero, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                vote8ab(acc, d, va[8], vb[8], va[9], vb[9], va[10], vb[10], va[11], vb[11], va[12], vb[12], va[13],
+                vote8ab(FOLD ? acc[t] : cnt[t], dmn[t], va[8], vb[8], va[9], vb[9], va[10], vb[10], va[11], vb[11], va[12], vb[12], va[13],
                         vb[13], va[14], vb[14], va[15], vb[15]);
-                if (FOLD1) {
-                    const bool bad = !(d >= BAND_CLEAN);
-                    cnt[t] += bad ? 0u : acc;
-                    dmn[t] = __uint_as_float(__float_as_uint(dmn[t]) | ((bad ? 1u : 0u) << tile));
-                } else {
-                    cnt[t] = acc;
-                    dmn[t] = d;
+                if (FOLD && close) {  // close the cell: its votes count only if no test of it lies inside the band
+                    const bool bad = !(dmn[t] >= BAND_CLEAN);
+                    cnt[t] += bad ? (1u << (tile / (FOLD ? FOLD : 1))) : acc[t];  // (a flag bit never carries: one add per group)
+                    acc[t] = 0u;
+                    dmn[t] = 3.0e38f;
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 va = va2;
@@ -1167,7 +1174,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             Ab = Nb;
         }
         // ---- clean cells: their counts; flagged cells: into the item's list
-        const unsigned all_tiles = (1u << nti) - 1u;  // nti <= 16
+        const unsigned all_groups = 1u;  // FOLD = 0: the one cell of the item
         int colx = col;  // opaque copy: keeps the eight per-tile addresses below from being hoisted above the scoring loop,
         asm volatile("" : "+v"(colx));  // where they would cost 20 VGPRs at the point of highest pressure
         int32_t* const pcnt = P.counts + bk * P.hn_pad + h0;
@@ -1175,13 +1182,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         for (int t = 0; t < MH; ++t) {
             unsigned mask;
             int votes;
-            if (FOLD1) {
+            if (FOLD) {
                 votes = votes_of(cnt[t]);   // <= 16 * 16 clean votes, wrapped mod 512
-                mask = __float_as_uint(dmn[t]);
+                mask = cnt[t] & 0xFFFFu;
             } else {
                 const bool bad = !(dmn[t] >= BAND_CLEAN);
                 votes = bad ? 0 : votes_of(cnt[t]);
-                mask = bad ? all_tiles : 0u;
+                mask = bad ? all_groups : 0u;
             }
             const int c = half_wave_sum(votes);  // the half-waves hold different rows of the column
             if (half == 0 && c > 0) atomicAdd(pcnt + t * 32 + colx, c);
@@ -1211,11 +1218,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 const int row = (q >> 2) * 8 + hf * 4 + (q & 3);  // the 16 rows a lane of that half-wave holds
                 int votes = 0;
                 while (m) {
-                    const int tile = __ffs((int)m) - 1;
+                    const int g = __ffs((int)m) - 1;  // a group of FOLD pixel tiles (FOLD = 0: all of the item's)
                     m &= m - 1u;
-                    const float4 r = s_raw[tile * 32 + row];
-                    votes += inlier_literal(r.x, r.y, r.z, r.w, hv.x, hv.y, P.thresh) ? 1 : 0;
-                    ++ntests;
+                    const int t0 = FOLD ? g * FOLD : 0, t1 = FOLD ? (t0 + FOLD < nti ? t0 + FOLD : nti) : nti;
+                    for (int tile = t0; tile < t1; ++tile) {
+                        const float4 r = s_raw[tile * 32 + row];
+                        votes += inlier_literal(r.x, r.y, r.z, r.w, hv.x, hv.y, P.thresh) ? 1 : 0;
+                        ++ntests;
+                    }
                 }
                 votes += __shfl_xor(votes, 8, 64);
                 votes += __shfl_xor(votes, 4, 64);
@@ -1423,6 +1433,10 @@ __global__ __launch_bounds__(256) void confidence_kernel(VoteParams P, const flo
     PVNET_SPARE_VGPRS(47);
     const int k = blockIdx.x, bi = blockIdx.y;
     const size_t bk = (size_t)bi * P.vn + k;
+    if (P.ctrl[P.b * CTRL_STRIDE + 6] != P.layout_fp) {  // the workspace was written under another layout (tuning reloaded)
+        if (threadIdx.x == 0) conf[bk] = __uint_as_float(0x7FC00000u);
+        return;
+    }
     const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
     const bool live = P.ctrl[bi * CTRL_STRIDE + C_NCHUNKS] > 0;
     const float px = pts[bk * 2], py = pts[bk * 2 + 1];
@@ -1447,6 +1461,10 @@ __global__ __launch_bounds__(256) void distribution_kernel(VoteParams P, const f
     PVNET_SPARE_VGPRS(47);
     const int k = blockIdx.x, bi = blockIdx.y;
     const size_t bk = (size_t)bi * P.vn + k;
+    if (P.ctrl[P.b * CTRL_STRIDE + 6] != P.layout_fp) {  // the workspace was written under another layout (tuning reloaded)
+        if (threadIdx.x < 4) cov[bk * 4 + threadIdx.x] = __uint_as_float(0x7FC00000u);
+        return;
+    }
     const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
     const bool live = P.ctrl[bi * CTRL_STRIDE + C_NCHUNKS] > 0;
     const float mx = mean[bk * 2], my = mean[bk * 2 + 1];
@@ -1707,6 +1725,20 @@ int band_fold1(int forced, float thresh) {
     return thresh > 0.95f ? 1 : 0;
 }
 
+// the workspace layout depends on process-wide tuning (score mode, count atomics, chunk, hpl), which
+// pvnet_vote_tuning_reload() may change between a vote and an epilogue that reads the vote's workspace.  Every vote stamps
+// the layout it used into ctrl's global row; the epilogue kernels compare it with the layout THEY were handed and answer NaN
+// instead of reading the old workspace at new offsets.
+int layout_fingerprint(const PvnetVoteLayout& L) {
+    uint64_t x = 0x9E3779B97F4A7C15ull;
+    const uint64_t v[] = {(uint64_t)L.chunk, (uint64_t)L.hpl, (uint64_t)L.wg_g, (uint64_t)L.reserved_, (uint64_t)L.cap,
+                          (uint64_t)L.hn_pad, (uint64_t)L.off_rec, (uint64_t)L.off_hyp, (uint64_t)L.off_counts,
+                          (uint64_t)L.off_win, (uint64_t)L.total_bytes};
+    for (uint64_t e : v) { x ^= e + 0x9E3779B97F4A7C15ull + (x << 6) + (x >> 2); }
+    const int fp = (int)(x ^ (x >> 32));
+    return fp ? fp : 1;
+}
+
 int env_int(const char* name, int dflt) {
     const char* s = getenv(name);
     return (s && *s) ? atoi(s) : dflt;
@@ -1850,15 +1882,15 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
             const size_t lds = (size_t)(npx / 32) * TILE_U4 * sizeof(uint4) + (size_t)npx * sizeof(float4) +
                                (size_t)4 * mh * 32 * sizeof(float2) + (size_t)4 * mh * 64 * sizeof(unsigned);
             const dim3 g((unsigned)wgs), t(256);
-            const bool fold1 = P.fold1 != 0;
+            const int fold = P.fold1;
 #define PV_EXACT(MH_)                                                                                               \
     do {                                                                                                            \
         if (timed_score) {                                                                                          \
-            if (fold1) hipLaunchKernelGGL((score_exact_kernel<MH_, true, true>), g, t, lds, s, P);                  \
-            else hipLaunchKernelGGL((score_exact_kernel<MH_, false, true>), g, t, lds, s, P);                       \
+            if (fold == 1) hipLaunchKernelGGL((score_exact_kernel<MH_, 1, true>), g, t, lds, s, P);                 \
+            else hipLaunchKernelGGL((score_exact_kernel<MH_, 0, true>), g, t, lds, s, P);                           \
         } else {                                                                                                    \
-            if (fold1) hipLaunchKernelGGL((score_exact_kernel<MH_, true, false>), g, t, lds, s, P);                 \
-            else hipLaunchKernelGGL((score_exact_kernel<MH_, false, false>), g, t, lds, s, P);                      \
+            if (fold == 1) hipLaunchKernelGGL((score_exact_kernel<MH_, 1, false>), g, t, lds, s, P);                \
+            else hipLaunchKernelGGL((score_exact_kernel<MH_, 0, false>), g, t, lds, s, P);                          \
         }                                                                                                           \
     } while (0)
             switch (mh) {
@@ -1935,6 +1967,7 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     P.words = L.words; P.cap = L.cap; P.chunk = L.chunk; P.max_chunks = L.max_chunks;
     P.hpl = L.hpl; P.hgroups = L.hgroups; P.hn_pad = L.hn_pad; P.wg_g = L.wg_g; P.wg_s = L.wg_s;
     P.mode = L.reserved_;
+    P.layout_fp = layout_fingerprint(L);
     P.score_xcd = tuning().score_xcd;
     P.atomic_counts = tuning().score_atomic;
     P.thresh = thresh;

@@ -682,3 +682,51 @@ def test_single_hypothesis_and_single_keypoint():
     np.testing.assert_array_equal(dbg["win"][:, :, 1].cpu().numpy(), wc)
     ok = (st.cpu().numpy() == 0)
     assert np.abs(out.cpu().numpy() - ref)[ok].max() < TOL_PX
+
+
+# ------------------------------------------------------------------------------------------------ threads
+def test_four_python_threads_vote_concurrently_like_dataparallel():
+    """the reference's multi-GPU path is `nn.DataParallel(EvalWrapper)` (tools/demo.py:174,
+    tools/train_linemod.py:183-184) -- one Python thread per replica calling the voting layer at the same time.  The
+    ctypes call releases the GIL, so four threads really are inside the library together: each votes its own batches on
+    its own stream with its own workspace, 12 calls each, interleaved with the others'; every result must be bit-equal to
+    the same call made serially (the library has no state between calls besides the read-only tuning table)."""
+    import threading
+    nthreads, calls = 4, 12
+    sets = []
+    for t in range(nthreads):
+        mask, planar, _ = synth.make_batch(3, first_index=9000 + 10 * t, h=200 + 8 * t, w=280, radius=24 + t, noise=True,
+                                           background="normal")
+        sets.append(to_dev(mask, planar))
+    hn = [256, 300, 512, 128]
+    serial = [[voting.ransac_voting_layer_v3(m, v, hn[t], inlier_thresh=0.99, seed=100 * t + c).clone()
+               for c in range(calls)] for t, (m, v) in enumerate(sets)]
+    torch.cuda.synchronize()
+    results = [[None] * calls for _ in range(nthreads)]
+    errors = []
+    gate = threading.Barrier(nthreads)
+
+    def worker(t):
+        try:
+            m, v = sets[t]
+            st = torch.cuda.Stream()
+            L = voting.vote_layout(m.shape[0], m.shape[1], m.shape[2], 9, hn[t], 30000)
+            ws = torch.empty(L.total_bytes, dtype=torch.uint8, device=m.device)
+            gate.wait()
+            with torch.cuda.stream(st):
+                for c in range(calls):
+                    results[t][c] = voting.ransac_voting_layer_v3(m, v, hn[t], inlier_thresh=0.99, seed=100 * t + c,
+                                                                  workspace=ws).clone()
+            st.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(nthreads):
+        for c in range(calls):
+            assert torch.equal(results[t][c], serial[t][c]), (t, c)

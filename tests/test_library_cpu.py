@@ -40,7 +40,7 @@ def test_host_pnp_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "pvnet_pnp.h")).read()
     body = hdr[hdr.index('extern "C"'):]
     names = set(re.findall(r"^(?:void|int)\s+([a-z0-9_]+)\s*\(", body, flags=re.M))
-    assert {"uncertainty_pnp", "pvnet_pnp_refine", "pvnet_pnp_solve", "pvnet_pnp_solve_batch",
+    assert {"uncertainty_pnp", "pvnet_pnp_refine", "pvnet_pnp_evaluate", "pvnet_pnp_solve", "pvnet_pnp_solve_batch",
             "pvnet_angle_axis_to_matrix", "pvnet_matrix_to_angle_axis", "farthest_point_sampling",
             "farthest_point_sampling_init_center"} == names
     for n in names:
@@ -49,7 +49,7 @@ def test_host_pnp_library_exports_every_declared_symbol():
 
 def test_library_contains_gfx950_code_object():
     blob = open(voting.LIB_PATH, "rb").read()
-    assert b"gfx950" in blob and b"score_kernel" in blob and b"score_mfma_kernel" in blob
+    assert b"gfx950" in blob and b"score_kernel" in blob and b"score_mfma_kernel" in blob and b"score_exact_kernel" in blob
 
 
 def test_layout_baseline_config(lib):
