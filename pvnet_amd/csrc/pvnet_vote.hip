@@ -24,8 +24,8 @@
 //                     three bf16 parts, so each dot product is ONE v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
 //                     EXACT mode (default, score_exact_kernel): the two MFMAs return a = dt - cr and b = dt + cr in units of
 //                     the float32 rounding band of the reference's test; the lane that owns the hypothesis takes
-//                     t = clamp(min(a, b)) (the vote, exactly 1.0f / 0 outside the band), sums two t's per wrapping
-//                     v_add3_u32 and keeps min |a|, |b| (v_min3_f32): 2 MFMAs + 2.5 VALU ops per test (vote8ab); cells
+//                     x = min(a, b, 1) (exactly 1.0f for a vote, <= -1 for a non-vote outside the band), keeps min |x|
+//                     and counts the votes from packed-norm halves: 2 MFMAs + 2.25 VALU ops per test (vote8x); cells
 //                     that hold a test inside the band are re-evaluated with the reference's own arithmetic
 //                     (inlier_literal) from the raw records, so every inlier count EQUALS the reference kernel's.
 //                     APPROX mode (PVNET_F_APPROX, score_mfma_kernel): t = clamp(dt - |cr|) on 2^60-scaled records,
@@ -275,14 +275,14 @@ __device__ __forceinline__ void b_col(float x, float y, uint4& lo, uint4& hi) {
 //     A row    scaled by  sigma_i = (rho / (rho + r_i)) / |u_i|       (any float: the direction is normalised as well)
 // give  |s_j sigma_i m| < 1  for every pair inside the band -- also as the matrix pipe computes it.  The two MFMAs return
 //     a' = s sigma (dt - cr),   b' = s sigma (dt + cr)        (dt - |cr| = min(a, b): the |.| is gone from the epilogue)
-// so that  t = clamp(min(a', b'))  [one v_min_f32 with the clamp modifier] is EXACTLY 1.0f for a vote outside the band and
-// 0.0f for a non-vote outside the band, and  dmin = min(dmin, |a'|, |b'|)  [one v_min3_f32] is < 1 whenever a test of the
-// cell lies inside the band (|min(a', b')| is one of |a'|, |b'|).  Cells with dmin >= 1 hold only tests on which the
-// reference's arithmetic and exact arithmetic agree, and their votes are counted as in the approximate mode (two t's per
-// v_add3_u32); a cell with dmin < 1 is re-evaluated with inlier_literal() from the raw records and its t's are discarded.
-// = 2.5 full-rate VALU operations per test (1.5 in the approximate mode).  Measured alternatives (tools/ubench_exact.hip,
-// profiles/r03_ubench_exact.txt): a float16 ramp (v_fma_mixlo/hi_f16) with byte moments (v_perm_b32 + v_dot4_u32_u8) is
-// 1.75 operations per test on paper but VOP3P instructions issue at half rate on gfx950: 12.3 T tests/s against 18.3 T.
+// so that  x = min(a', b', 1)  [one v_min3_f32] is EXACTLY 1.0f for a vote outside the band, <= -1 for a non-vote outside
+// the band and strictly between for a test inside it.  Cells with min |x| >= 1 hold only tests on which the reference's
+// arithmetic and exact arithmetic agree, and their votes are counted from the x's (vote8x); a cell with min |x| < 1 is
+// re-evaluated with inlier_literal() from the raw records and its x's are discarded.
+// = 2.25 VALU operations per test (1.5 in the approximate mode).  Measured alternatives (tools/ubench_exact.hip,
+// profiles/r03_ubench_exact.txt): t = clamp(min(a', b')) + min3(|a'|, |b'|) + add3 on float patterns, 2.5 operations:
+// 12.8 T tests/s against this form's 13.8 T; a float16 ramp (v_fma_mixlo/hi_f16) with byte moments (v_perm_b32 +
+// v_dot4_u32_u8), 1.75 operations on paper: 11.5 T -- VOP3P instructions issue at about half rate on gfx950.
 // Range gates: |h - o| >= 2^61 (or not finite) and |u| >= 2^61 would overflow the reference's squares -- such columns /
 // rows are sent as zeros: a' = b' = 0 flags every cell they touch, which is then decided by the reference's arithmetic
 // itself, whatever that does.  Zero records (padding, |u| < 1e-6) and NaN / Inf directions never vote in the reference;
@@ -1033,44 +1033,121 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
 // K4 (exact mode, the default): the matrix-pipe scoring of score_mfma_kernel with the rounding-band epilogue
 // described above b_col_exact(): counts EQUAL to the reference kernel's, 2.5 VALU operations per test.
 // ------------------------------------------------------------------------------------------------------------
-// Eight tests of the lane's hypothesis: t = clamp(min(a, b)) (the vote, exact outside the band), two of them per
-// v_add3_u32 into the wrapped counter of vote8(); dm = running minimum of |a|, |b| over the cell.
-__device__ __forceinline__ void vote8ab(unsigned& acc, float& dm, float a0, float b0, float a1, float b1, float a2, float b2,
-                                        float a3, float b3, float a4, float b4, float a5, float b5, float a6, float b6,
-                                        float a7, float b7) {
-    float t0, t1, t2;
+// Eight tests of the lane's hypothesis in 18 VALU operations (2.25 per test):
+//   x = min(a', b', 1)            v_min3_f32: exactly 1.0f = a vote outside the band, <= -1 = a non-vote outside the band,
+//                                 anything in between = a test inside the band (dt' - |cr'| = min(a', b'))
+//   dm = min(dm, |x|, |x'|)       v_min3_f32, two tests per instruction: the cell is clean iff dm >= 1
+//   w = pknorm_u16(x, x')         v_cvt_pknorm_u16_f32, two tests per instruction: clamp(x) * 65535 -> 0xFFFF for a vote, 0 else
+//   acc += w + w'                 v_add3_u32, four tests per instruction (wraps; votes_of_norm() decodes)
+// Measured beside the MFMAs (tools/ubench_exact.hip, profiles/r03_ubench_exact.txt): 13.8 T tests/s against 12.8 T for
+// "v_min clamp + v_min3 |a|, |b| + v_add3 on float patterns" (2.5 operations) and 16.7-18 T for the approximate mode's 1.5.
+__device__ __forceinline__ void vote8x(unsigned& acc, float& dm, float a0, float b0, float a1, float b1, float a2, float b2,
+                                       float a3, float b3, float a4, float b4, float a5, float b5, float a6, float b6,
+                                       float a7, float b7) {
+    float x0, x1, x2, x3;
+    unsigned w0, w1;
     asm volatile(
-        "v_min_f32_e64 %2, %5, %6 clamp\n"        // M0
-        "v_min_f32_e64 %3, %7, %8 clamp\n"        // M1
-        "v_min3_f32 %1, %1, |%5|, |%6|\n"         // D0
-        "v_min_f32_e64 %4, %9, %10 clamp\n"       // M2
-        "v_min3_f32 %1, %1, |%7|, |%8|\n"         // D1
-        "v_add3_u32 %0, %2, %3, %0\n"             // A01
-        "v_min_f32_e64 %2, %11, %12 clamp\n"      // M3
-        "v_min3_f32 %1, %1, |%9|, |%10|\n"        // D2
-        "v_min_f32_e64 %3, %13, %14 clamp\n"      // M4
-        "v_min3_f32 %1, %1, |%11|, |%12|\n"       // D3
-        "v_add3_u32 %0, %4, %2, %0\n"             // A23
-        "v_min_f32_e64 %4, %15, %16 clamp\n"      // M5
-        "v_min3_f32 %1, %1, |%13|, |%14|\n"       // D4
-        "v_min_f32_e64 %2, %17, %18 clamp\n"      // M6
-        "v_min3_f32 %1, %1, |%15|, |%16|\n"       // D5
-        "v_add3_u32 %0, %3, %4, %0\n"             // A45
-        "v_min_f32_e64 %3, %19, %20 clamp\n"      // M7
-        "v_min3_f32 %1, %1, |%17|, |%18|\n"       // D6
-        "v_min3_f32 %1, %1, |%19|, |%20|\n"       // D7
-        "v_add3_u32 %0, %2, %3, %0\n"             // A67
-        : "+v"(acc), "+v"(dm), "=&v"(t0), "=&v"(t1), "=&v"(t2)
+        "v_min3_f32 %2, %8, %9, 1.0\n"
+        "v_min3_f32 %3, %10, %11, 1.0\n"
+        "v_min3_f32 %4, %12, %13, 1.0\n"
+        "v_min3_f32 %5, %14, %15, 1.0\n"
+        "v_min3_f32 %1, %1, |%2|, |%3|\n"
+        "v_cvt_pknorm_u16_f32 %6, %2, %3\n"
+        "v_min3_f32 %2, %16, %17, 1.0\n"
+        "v_min3_f32 %3, %18, %19, 1.0\n"
+        "v_min3_f32 %1, %1, |%4|, |%5|\n"
+        "v_cvt_pknorm_u16_f32 %7, %4, %5\n"
+        "v_min3_f32 %4, %20, %21, 1.0\n"
+        "v_min3_f32 %5, %22, %23, 1.0\n"
+        "v_add3_u32 %0, %6, %7, %0\n"
+        "v_min3_f32 %1, %1, |%2|, |%3|\n"
+        "v_cvt_pknorm_u16_f32 %6, %2, %3\n"
+        "v_min3_f32 %1, %1, |%4|, |%5|\n"
+        "v_cvt_pknorm_u16_f32 %7, %4, %5\n"
+        "v_add3_u32 %0, %6, %7, %0\n"
+        : "+v"(acc), "+v"(dm), "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(w0), "=&v"(w1)
         : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5),
           "v"(a6), "v"(b6), "v"(a7), "v"(b7));
+}
+// votes in a vote8x accumulator: acc = 0xFFFF v_lo + 65536 * 0xFFFF v_hi (mod 2^32) for v_lo / v_hi votes in the low / high
+// halves (even / odd tests), i.e. acc = 65536 (v_lo - v_hi) - v_lo: both counts < 65536 are recovered exactly
+__device__ __forceinline__ int votes_of_norm(unsigned acc) {
+    const unsigned lo = (0u - acc) & 0xFFFFu;
+    const unsigned hi = (lo - ((acc + lo) >> 16)) & 0xFFFFu;
+    return (int)(lo + hi);
+}
+// FOLD = 1 (one cell per step): the first eight tests OPEN the cell -- acc and dm are produced, not updated, which saves their
+// two initialisations -- and the second eight CLOSE it: the cell's votes join cnt only if no |x| fell below 1, and the
+// verdict is shifted into flg (v_addc_co_u32 flg = 2 flg + bad: after the item's tiles bit (nti - 1 - tile) belongs to
+// `tile`).  22 operations for the closing half: 40 per step against 36 + 7 for the same in C.
+__device__ __forceinline__ void vote8x_open(unsigned& acc, float& dm, float a0, float b0, float a1, float b1, float a2,
+                                            float b2, float a3, float b3, float a4, float b4, float a5, float b5, float a6,
+                                            float b6, float a7, float b7) {
+    float x0, x1, x2, x3;
+    unsigned w0, w1;
+    asm volatile(
+        "v_min3_f32 %2, %8, %9, 1.0\n"
+        "v_min3_f32 %3, %10, %11, 1.0\n"
+        "v_min3_f32 %4, %12, %13, 1.0\n"
+        "v_min3_f32 %5, %14, %15, 1.0\n"
+        "v_min_f32_e64 %1, |%2|, |%3|\n"
+        "v_cvt_pknorm_u16_f32 %6, %2, %3\n"
+        "v_min3_f32 %2, %16, %17, 1.0\n"
+        "v_min3_f32 %3, %18, %19, 1.0\n"
+        "v_min3_f32 %1, %1, |%4|, |%5|\n"
+        "v_cvt_pknorm_u16_f32 %7, %4, %5\n"
+        "v_min3_f32 %4, %20, %21, 1.0\n"
+        "v_min3_f32 %5, %22, %23, 1.0\n"
+        "v_add_u32_e32 %0, %6, %7\n"
+        "v_min3_f32 %1, %1, |%2|, |%3|\n"
+        "v_cvt_pknorm_u16_f32 %6, %2, %3\n"
+        "v_min3_f32 %1, %1, |%4|, |%5|\n"
+        "v_cvt_pknorm_u16_f32 %7, %4, %5\n"
+        "v_add3_u32 %0, %6, %7, %0\n"
+        : "=&v"(acc), "=&v"(dm), "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(w0), "=&v"(w1)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5),
+          "v"(a6), "v"(b6), "v"(a7), "v"(b7));
+}
+__device__ __forceinline__ void vote8x_close(unsigned& cnt, unsigned& flg, unsigned acc, float dm, float a0, float b0,
+                                             float a1, float b1, float a2, float b2, float a3, float b3, float a4, float b4,
+                                             float a5, float b5, float a6, float b6, float a7, float b7) {
+    float x0, x1, x2, x3;
+    unsigned w0, w1;
+    asm volatile(
+        "v_min3_f32 %4, %10, %11, 1.0\n"
+        "v_min3_f32 %5, %12, %13, 1.0\n"
+        "v_min3_f32 %6, %14, %15, 1.0\n"
+        "v_min3_f32 %7, %16, %17, 1.0\n"
+        "v_min3_f32 %3, %3, |%4|, |%5|\n"
+        "v_cvt_pknorm_u16_f32 %8, %4, %5\n"
+        "v_min3_f32 %4, %18, %19, 1.0\n"
+        "v_min3_f32 %5, %20, %21, 1.0\n"
+        "v_min3_f32 %3, %3, |%6|, |%7|\n"
+        "v_cvt_pknorm_u16_f32 %9, %6, %7\n"
+        "v_min3_f32 %6, %22, %23, 1.0\n"
+        "v_min3_f32 %7, %24, %25, 1.0\n"
+        "v_add3_u32 %2, %8, %9, %2\n"
+        "v_min3_f32 %3, %3, |%4|, |%5|\n"
+        "v_cvt_pknorm_u16_f32 %8, %4, %5\n"
+        "v_min3_f32 %3, %3, |%6|, |%7|\n"
+        "v_cvt_pknorm_u16_f32 %9, %6, %7\n"
+        "v_cmp_nle_f32_e32 vcc, 1.0, %3\n"       // bad = !(dm >= 1)   (NaN cannot occur: |x| of finite x)
+        "v_add3_u32 %2, %8, %9, %2\n"
+        "s_nop 0\n"
+        "v_cndmask_b32_e64 %2, %2, 0, vcc\n"     // the cell's votes, or nothing
+        "v_addc_co_u32_e32 %1, vcc, %1, %1, vcc\n"   // flg = 2 flg + bad
+        "v_add_u32_e32 %0, %0, %2\n"
+        : "+v"(cnt), "+v"(flg), "+v"(acc), "+v"(dm), "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(w0), "=&v"(w1)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5),
+          "v"(a6), "v"(b6), "v"(a7), "v"(b7)
+        : "vcc");
 }
 constexpr float BAND_CLEAN = 1.0f;     // a cell whose minimum |a'|, |b'| reaches this holds no test inside the band
 
 // FOLD = 0: one cell per (lane, hypothesis tile) and work item -- the minimum runs over all the item's pixel tiles
 //           (cheapest epilogue; right when flagged cells are very rare: loose thresholds, band_fold());
-// FOLD = F: one cell per (lane, hypothesis tile, F consecutive PIXEL tiles) -- the test is made after every F-th tile (five
-//           more VALU operations each time), and a flagged cell costs 16 F literal tests instead of 16 * tiles.  F = 1 is
-//           built; F = 2 measured no better on paper and keeps 17 more VGPRs live (the spare-granule rule fails).
+// FOLD = 1: one cell per (lane, hypothesis tile, PIXEL tile) -- the test is made after every step (four more VALU operations,
+//           vote8x_open / vote8x_close), and a flagged cell costs 16 literal tests instead of 16 * tiles.
 template <int MH, int FOLD, bool TIMED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void score_exact_kernel(VoteParams P) {
     if (MH == 8) PVNET_SPARE_VGPRS(167); else if (MH == 4) PVNET_SPARE_VGPRS(143); else PVNET_SPARE_VGPRS(111);
@@ -1129,14 +1206,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             if (tid + 256 * j < 4 * MH * 32) s_hyp[tid + 256 * j] = hreg[j];
         __syncthreads();
 
-        unsigned cnt[MH];   // wrapped vote counters of the clean cells (vote8)
+        unsigned cnt[MH];   // wrapped vote counters of the clean cells (vote8x / votes_of_norm)
         float dmn[MH];      // min |a'|, |b'| of the open cell so far
-        unsigned acc[MH];   // FOLD: wrapped votes of the open cell
-        // FOLD: the low 16 bits of cnt[t] (always zero in a wrapped vote counter: multiples of 0x3F800000) carry the flags:
-        // bit g set = the g-th group of FOLD pixel tiles holds a test inside the band
+        unsigned flg[MH];   // FOLD: bit (nti - 1 - tile) set = pixel tile `tile` holds a test inside the band
 #pragma unroll
         for (int t = 0; t < MH; ++t) {
-            cnt[t] = acc[t] = 0u;
+            cnt[t] = flg[t] = 0u;
             dmn[t] = 3.0e38f;
         }
         bf16x8 Aa = __builtin_bit_cast(bf16x8, lbase[0]), Ab = __builtin_bit_cast(bf16x8, lbase[64]);
@@ -1148,24 +1223,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             const int nt = tile + 1 < nti ? tile + 1 : tile;
             const bf16x8 Na = __builtin_bit_cast(bf16x8, lbase[nt * TILE_U4]);
             const bf16x8 Nb = __builtin_bit_cast(bf16x8, lbase[nt * TILE_U4 + 64]);
-            const bool close = FOLD && ((tile + 1) % (FOLD ? FOLD : 1) == 0 || tile + 1 == nti);  // (wave-uniform)
 #pragma unroll
             for (int t = 0; t < MH; ++t) {
+                unsigned acc = 0u;    // FOLD: the open cell's votes / minimum
+                float dmo = 0.f;
                 const f32x16 va2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Aa : Na, B[(t + 1) % MH], zero, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                vote8ab(FOLD ? acc[t] : cnt[t], dmn[t], va[0], vb[0], va[1], vb[1], va[2], vb[2], va[3], vb[3], va[4], vb[4], va[5], vb[5],
-                        va[6], vb[6], va[7], vb[7]);
+                if (FOLD)
+                    vote8x_open(acc, dmo, va[0], vb[0], va[1], vb[1], va[2], vb[2], va[3], vb[3], va[4], vb[4], va[5], vb[5],
+                                va[6], vb[6], va[7], vb[7]);
+                else
+                    vote8x(cnt[t], dmn[t], va[0], vb[0], va[1], vb[1], va[2], vb[2], va[3], vb[3], va[4], vb[4], va[5], vb[5],
+                           va[6], vb[6], va[7], vb[7]);
                 __builtin_amdgcn_sched_barrier(0);
                 const f32x16 vb2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Ab : Nb, B[(t + 1) % MH], zero, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                vote8ab(FOLD ? acc[t] : cnt[t], dmn[t], va[8], vb[8], va[9], vb[9], va[10], vb[10], va[11], vb[11], va[12], vb[12], va[13],
-                        vb[13], va[14], vb[14], va[15], vb[15]);
-                if (FOLD && close) {  // close the cell: its votes count only if no test of it lies inside the band
-                    const bool bad = !(dmn[t] >= BAND_CLEAN);
-                    cnt[t] += bad ? (1u << (tile / (FOLD ? FOLD : 1))) : acc[t];  // (a flag bit never carries: one add per group)
-                    acc[t] = 0u;
-                    dmn[t] = 3.0e38f;
-                }
+                if (FOLD)
+                    vote8x_close(cnt[t], flg[t], acc, dmo, va[8], vb[8], va[9], vb[9], va[10], vb[10], va[11], vb[11], va[12],
+                                 vb[12], va[13], vb[13], va[14], vb[14], va[15], vb[15]);
+                else
+                    vote8x(cnt[t], dmn[t], va[8], vb[8], va[9], vb[9], va[10], vb[10], va[11], vb[11], va[12], vb[12], va[13],
+                           vb[13], va[14], vb[14], va[15], vb[15]);
                 __builtin_amdgcn_sched_barrier(0);
                 va = va2;
                 vb = vb2;
@@ -1183,11 +1261,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             unsigned mask;
             int votes;
             if (FOLD) {
-                votes = votes_of(cnt[t]);   // <= 16 * 16 clean votes, wrapped mod 512
-                mask = cnt[t] & 0xFFFFu;
+                votes = votes_of_norm(cnt[t]);
+                mask = flg[t];
             } else {
                 const bool bad = !(dmn[t] >= BAND_CLEAN);
-                votes = bad ? 0 : votes_of(cnt[t]);
+                votes = bad ? 0 : votes_of_norm(cnt[t]);
                 mask = bad ? all_groups : 0u;
             }
             const int c = half_wave_sum(votes);  // the half-waves hold different rows of the column
@@ -1218,9 +1296,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 const int row = (q >> 2) * 8 + hf * 4 + (q & 3);  // the 16 rows a lane of that half-wave holds
                 int votes = 0;
                 while (m) {
-                    const int g = __ffs((int)m) - 1;  // a group of FOLD pixel tiles (FOLD = 0: all of the item's)
+                    const int g = __ffs((int)m) - 1;  // FOLD: bit g = pixel tile nti - 1 - g (vote8x_close shifts them in)
                     m &= m - 1u;
-                    const int t0 = FOLD ? g * FOLD : 0, t1 = FOLD ? (t0 + FOLD < nti ? t0 + FOLD : nti) : nti;
+                    const int t0 = FOLD ? nti - 1 - g : 0, t1 = FOLD ? t0 + 1 : nti;
                     for (int tile = t0; tile < t1; ++tile) {
                         const float4 r = s_raw[tile * 32 + row];
                         votes += inlier_literal(r.x, r.y, r.z, r.w, hv.x, hv.y, P.thresh) ? 1 : 0;
@@ -1716,13 +1794,14 @@ float band_constant(float thresh) {
     const double k_fast = u * (1.0 + tau) * (1.43 * 10.0 + 8.0);
     return (float)(k_lit + k_fast);
 }
-// cell size of the exact mode: one pixel tile (16 tests per lane) unless the threshold is so loose that hardly any test
-// falls into the band.  Measured at the benchmark shape (tools/exact_probe.py, profiles/r03_exact_probe.txt): thresh 0.9 --
-// item cells 146 us, tile cells 152 us; 0.99 -- 190 / 177 us; 0.999 -- 340 / 200 us (the threshold angle, 2.6 degrees,
-// sits inside the field's noise there: 6e-4 of the tests are re-evaluated).
+// cell size of the exact mode: one pixel tile (16 tests per lane; vote8x_open / vote8x_close, 40 VALU operations per step)
+// by default; PVNET_EXACT_FOLD=0 selects one cell per work item (36 operations per step, but a flagged cell re-evaluates
+// 16 x tiles tests).  Measured at the benchmark shape (tools/exact_probe.py, profiles/r03_exact_probe.txt), item / tile
+// cells: thresh 0.9 -- 135 / 137 us; 0.99 -- 169 / 158 us; 0.999 -- 313 / 184 us (the threshold angle, 2.6 degrees, sits
+// inside the field's noise there: 6e-4 of the tests are re-evaluated); approximate mode on the same box: 90-102 us.
 int band_fold1(int forced, float thresh) {
-    if (forced == 0 || forced == 1) return forced;
-    return thresh > 0.95f ? 1 : 0;
+    (void)thresh;
+    return forced == 0 ? 0 : 1;
 }
 
 // the workspace layout depends on process-wide tuning (score mode, count atomics, chunk, hpl), which
@@ -1952,7 +2031,8 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     if (ws_bytes < L.total_bytes) return PVNET_E_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(ws) & 255u) != 0) return PVNET_E_BADARG;
     // the sqrt-free predicate folds 1/thresh into the records: needs thresh > 0; otherwise score literally
-    if (!(thresh > 0.f && thresh < 1.f)) flags |= PVNET_F_LITERAL;
+    // (and tau = sqrt(1 - t^2) / t below ~1e3, or the scaled matrix operands leave float32's range)
+    if (!(thresh >= 1e-3f && thresh < 1.f)) flags |= PVNET_F_LITERAL;
     char* base = static_cast<char*>(ws);
     P.mask = mask; P.ms0 = ms[0]; P.ms1 = ms[1]; P.ms2 = ms[2];
     P.ms_c = 0; P.num_classes = 1;  // only the logits entry point sets these

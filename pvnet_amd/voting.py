@@ -15,6 +15,7 @@ CPU tensors, these functions raise ``RuntimeError`` exactly like the reference's
 from __future__ import annotations
 
 import ctypes as C
+import struct
 import os
 from typing import Optional
 
@@ -179,11 +180,11 @@ def _debug_views(ws: torch.Tensor, L: Layout):
 
 
 def effective_literal(literal: bool, inlier_thresh: float) -> bool:
-    """the scoring mode a call really runs in: the sqrt-free fast predicate folds 1/thresh into the records and needs
-    0 < thresh < 1; outside that range the library scores literally (fill_params, pvnet_vote.hip) -- and then leaves
-    LITERAL-format records (x, y, ux, uy) in the workspace, which every consumer of that workspace must know."""
+    """the scoring mode a call really runs in: the matrix-pipe modes fold tan(acos(thresh)) into their operands and need
+    1e-3 <= thresh < 1; outside that range the library scores literally (fill_params, pvnet_vote.hip)."""
     t = float(inlier_thresh)
-    return bool(literal) or not (0.0 < t < 1.0)
+    t32 = struct.unpack('f', struct.pack('f', t))[0]  # the library compares the float32 it receives
+    return bool(literal) or not (struct.unpack('f', struct.pack('f', 1e-3))[0] <= t32 < 1.0)
 
 
 def mode_flags(literal: bool, approx: bool, inlier_thresh: float) -> int:

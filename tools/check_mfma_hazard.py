@@ -1,4 +1,4 @@
-"""Build-time check of the matrix-pipe scoring kernels' hand-placed vote epilogues (pvnet_vote.hip: vote8, vote8ab).
+"""Build-time check of the matrix-pipe scoring kernels' hand-placed vote epilogues (pvnet_vote.hip: vote8, vote8x).
 
 vote8 reads MFMA result VGPRs from inside an inline-asm block.  LLVM inserts the gfx950 "XDL write VGPR -> VALU read"
 wait states only for instructions IT schedules; what an INLINEASM block reads is invisible to its hazard recogniser,

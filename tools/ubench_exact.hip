@@ -270,6 +270,45 @@ __device__ __forceinline__ void ab_min3_noabs(unsigned& acc, float& d0, float& d
         : "+v"(acc), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "=&v"(t0), "=&v"(t1), "=&v"(t2)
         : AB_IN);
 }
+
+// EPI 9: x = min(a, b, 1) (1.0 = vote, <= -1 = clean non-vote, in between = inside the band); band = min |x| (two x per
+// v_min3); votes = v_cvt_pknorm_u16_f32 packs two clamp(x) as 0xFFFF / 0 halves, two such words per v_add3_u32: 2.25 op/test
+__device__ __forceinline__ void ab_x(unsigned& acc, float& dm, AB_ARGS) {
+    float x0, x1, x2, x3;
+    unsigned w0, w1;
+    asm volatile(
+        "v_min3_f32 %2, %8, %9, 1.0\n"
+        "v_min3_f32 %3, %10, %11, 1.0\n"
+        "v_min3_f32 %4, %12, %13, 1.0\n"
+        "v_min3_f32 %5, %14, %15, 1.0\n"
+        "v_min3_f32 %1, %1, |%2|, |%3|\n"
+        "v_cvt_pknorm_u16_f32 %6, %2, %3\n"
+        "v_min3_f32 %2, %16, %17, 1.0\n"
+        "v_min3_f32 %3, %18, %19, 1.0\n"
+        "v_min3_f32 %1, %1, |%4|, |%5|\n"
+        "v_cvt_pknorm_u16_f32 %7, %4, %5\n"
+        "v_min3_f32 %4, %20, %21, 1.0\n"
+        "v_min3_f32 %5, %22, %23, 1.0\n"
+        "v_add3_u32 %0, %6, %7, %0\n"
+        "v_min3_f32 %1, %1, |%2|, |%3|\n"
+        "v_cvt_pknorm_u16_f32 %6, %2, %3\n"
+        "v_min3_f32 %1, %1, |%4|, |%5|\n"
+        "v_cvt_pknorm_u16_f32 %7, %4, %5\n"
+        "v_add3_u32 %0, %6, %7, %0\n"
+        : "+v"(acc), "+v"(dm), "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(w0), "=&v"(w1)
+        : AB_IN);
+}
+__global__ void k_semantics_x(const float* __restrict__ a, const float* __restrict__ b, unsigned* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float av[8], bv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { av[q] = a[i * 8 + q]; bv[q] = b[i * 8 + q]; }
+    unsigned acc = 0;
+    float dm = 3e38f;
+    ab_x(acc, dm, av[0], bv[0], av[1], bv[1], av[2], bv[2], av[3], bv[3], av[4], bv[4], av[5], bv[5], av[6], bv[6], av[7], bv[7]);
+    out[i * 2] = acc;
+    out[i * 2 + 1] = __builtin_bit_cast(unsigned, dm);
+}
 #define AB_HALF(o) d[o + 0], cr[o + 0], d[o + 1], cr[o + 1], d[o + 2], cr[o + 2], d[o + 3], cr[o + 3], d[o + 4], cr[o + 4], \
                    d[o + 5], cr[o + 5], d[o + 6], cr[o + 6], d[o + 7], cr[o + 7]
 
@@ -356,7 +395,8 @@ __global__ __launch_bounds__(256) void k_pipe(const u16* __restrict__ Bsrc, cons
                 else if (EPI == 5) ab_min2(s1[t], f0[t], f1, AB_HALF(0));
                 else if (EPI == 6) ab_uclamp(s1[t], s2[t], AB_HALF(0));
                 else if (EPI == 7) ab_vote_only(s1[t], AB_HALF(0));
-                else ab_min3_noabs(s1[t], f0[t], f1, f2, f3, AB_HALF(0));
+                else if (EPI == 8) ab_min3_noabs(s1[t], f0[t], f1, f2, f3, AB_HALF(0));
+                else ab_x(s1[t], f0[t], AB_HALF(0));
                 __builtin_amdgcn_sched_barrier(0);
                 const f32x16 d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Ad : Nd, B[(t + 1) % MH], zero, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -368,7 +408,8 @@ __global__ __launch_bounds__(256) void k_pipe(const u16* __restrict__ Bsrc, cons
                 else if (EPI == 5) ab_min2(s1[t], f0[t], f1, AB_HALF(8));
                 else if (EPI == 6) ab_uclamp(s1[t], s2[t], AB_HALF(8));
                 else if (EPI == 7) ab_vote_only(s1[t], AB_HALF(8));
-                else ab_min3_noabs(s1[t], f0[t], f1, f2, f3, AB_HALF(8));
+                else if (EPI == 8) ab_min3_noabs(s1[t], f0[t], f1, f2, f3, AB_HALF(8));
+                else ab_x(s1[t], f0[t], AB_HALF(8));
                 __builtin_amdgcn_sched_barrier(0);
                 cr = cr2;
                 d = d2;
@@ -437,6 +478,53 @@ int main() {
                n, bad8, bad16, nfrac, detect_miss, nvote);
         (void)h2f;
     }
+
+    {   // ---- 1b. semantics of the x = min3(a, b, 1) epilogue: votes decoded from the packed-norm sum, band from min |x|
+        const int n = 64 * 64;
+        std::vector<float> a(n * 8), b(n * 8);
+        for (int i = 0; i < n * 8; ++i) {
+            const int kind = rand() % 6;
+            float av, bv;
+            if (kind == 0) { av = 1.f + rnd() * 1e4f; bv = 1.f + rnd() * 1e4f; }                     // clean vote
+            else if (kind == 1) { av = -1.f - rnd() * 1e4f; bv = (rnd() - .5f) * 1e4f; }              // clean non-vote
+            else if (kind == 2) { av = 1.f; bv = 1.f + rnd(); }                                        // exactly at the edge: vote, clean
+            else if (kind == 3) { av = -1.f; bv = 5.f; }                                               // exactly -1: clean non-vote
+            else if (kind == 4) { av = (rnd() - .5f) * 1.99f; bv = 3.f + rnd(); }                       // inside the band
+            else { av = -4.f; bv = -4.f; }                                                            // padding row
+            if (rand() & 1) { float t = av; av = bv; bv = t; }
+            a[i] = av; b[i] = bv;
+        }
+        if (true) {  // one cell with a hypothesis-free of band tests only, to make sure clean cells exist
+            for (int q = 0; q < 8 * 64; ++q) { a[q] = q & 1 ? 2.f : -3.f; b[q] = 7.f; }
+        }
+        float *da, *db; unsigned* dout;
+        hipMalloc(&da, n * 32); hipMalloc(&db, n * 32); hipMalloc(&dout, n * 8);
+        hipMemcpy(da, a.data(), n * 32, hipMemcpyHostToDevice);
+        hipMemcpy(db, b.data(), n * 32, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_semantics_x, dim3(n / 64), dim3(64), 0, 0, da, db, dout);
+        std::vector<unsigned> out(n * 2);
+        hipMemcpy(out.data(), dout, n * 8, hipMemcpyDeviceToHost);
+        long clean = 0, wrong_votes = 0, wrong_band = 0;
+        for (int i = 0; i < n; ++i) {
+            int v_lo = 0, v_hi = 0;
+            float dm = 3e38f;
+            for (int q = 0; q < 8; ++q) {
+                const float x = fminf(fminf(a[i * 8 + q], b[i * 8 + q]), 1.f);
+                dm = fminf(dm, fabsf(x));
+                if (x >= 1.f) { if (q & 1) ++v_hi; else ++v_lo; }
+            }
+            const float got_dm = __builtin_bit_cast(float, out[i * 2 + 1]);
+            if ((got_dm >= 1.f) != (dm >= 1.f)) ++wrong_band;
+            if (dm >= 1.f) {  // clean cell: decode  acc = 0xFFFF v_lo + 65536 * 0xFFFF v_hi  (mod 2^32)
+                ++clean;
+                const unsigned acc = out[i * 2];
+                const unsigned lo = (0u - acc) & 0xFFFFu;                 // = v_lo
+                const unsigned hi = (lo - ((acc + lo) >> 16)) & 0xFFFFu;  // acc + v_lo = 65536 (v_lo - v_hi)  (mod 2^32)
+                if ((int)lo != v_lo || (int)hi != v_hi) { if (++wrong_votes <= 5) printf("  lane %d: acc %08x decodes to (%u, %u), expected (%d, %d)\n", i, acc, lo, hi, v_lo, v_hi); }
+            }
+        }
+        printf("x-epilogue semantics: %d cells of 8 tests, %ld clean; wrong band flags %ld, wrong vote decodes in clean cells %ld\n", n, clean, wrong_band, wrong_votes);
+    }
     // ---- 2. MFMA accumulation error
     {
         const int nb = 4096;
@@ -488,12 +576,12 @@ int main() {
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
         for (int wpc = 3; wpc <= 3; ++wpc)
-            for (int epi = 0; epi < 9; ++epi) {
+            for (int epi = 0; epi < 10; ++epi) {
                 const dim3 g(cus * wpc), b(256);
                 const int reps = 64;
                 auto launch = [&] {
 #define LAUNCH(E) case E: hipLaunchKernelGGL((k_pipe<MH, E>), g, b, ntiles * TILE_BYTES, 0, dB, dA, dc, ntiles, reps); break;
-                    switch (epi) { LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) }
+                    switch (epi) { LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) LAUNCH(9) }
 #undef LAUNCH
                 };
                 launch();
@@ -514,7 +602,8 @@ int main() {
                        epi == 2 ? "mix + dot2 moments        (2.0  op/test)" : epi == 3 ? "a/b: min-clamp, min3 x1 chain, add3 (2.5)" :
                        epi == 4 ? "a/b: min-clamp, min3 x4 chains, add3 (2.5)" : epi == 5 ? "a/b: min-clamp, 2 x min |.|, add3  (3.5)" :
                        epi == 6 ? "a/b: min-clamp, min|.|-clamp, 2 add3 (3.0)" : epi == 7 ? "a/b: min-clamp + add3 only        (1.5)" :
-                                  "a/b: min3 without |.|, 4 chains    (2.5)",
+                       epi == 8 ? "a/b: min3 without |.|, 4 chains    (2.5)" :
+                                  "a/b: x = min3(a, b, 1), min3 |x|, cvt_pknorm, add3 (2.25)",
                        best, tests / best / 1e9);
             }
     }
