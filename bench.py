@@ -160,7 +160,7 @@ def source_hash():
 
 
 def newest_profile(suffix):
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)))  # rNNx tags sort by round, then letter
     return files[-1] if files else None
 
 
