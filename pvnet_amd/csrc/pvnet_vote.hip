@@ -1958,8 +1958,9 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
         if (P.exact) {
             const int mh = P.wg_g * P.hpl / 2;
             const int npx = P.wg_s * P.chunk;
-            const size_t lds = (size_t)(npx / 32) * TILE_U4 * sizeof(uint4) + (size_t)npx * sizeof(float4) +
-                               (size_t)4 * mh * 32 * sizeof(float2) + (size_t)4 * mh * 64 * sizeof(unsigned);
+            size_t lds = (size_t)(npx / 32) * TILE_U4 * sizeof(uint4) + (size_t)npx * sizeof(float4) +
+                         (size_t)4 * mh * 32 * sizeof(float2) + (size_t)4 * mh * 64 * sizeof(unsigned);
+            if (T.score_lds_kb > 0 && T.score_lds_kb <= 64 && lds < (size_t)T.score_lds_kb * 1024) lds = (size_t)T.score_lds_kb * 1024;
             const dim3 g((unsigned)wgs), t(256);
             const int fold = P.fold1;
 #define PV_EXACT(MH_)                                                                                               \

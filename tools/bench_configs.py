@@ -122,10 +122,14 @@ def run_plan(name, b, radius, hn, thresh, max_num=30000, steps=300):
           f"{np.median(qlat):6.1f} us (min {min(qlat):.1f})", flush=True)
 
 
-run("headline (cfg 3): R=40 int64", 32, 40, 1024, 0.99)
+run("headline (cfg 3): R=40 int64  [exact, default]", 32, 40, 1024, 0.99)
+run("headline, approximate mode", 32, 40, 1024, 0.99, approx=True)
 run("uint8 mask", 32, 40, 1024, 0.99, mask_dtype=torch.uint8)
 run("thresh 0.999", 32, 40, 1024, 0.999)
+run("thresh 0.999, approximate mode", 32, 40, 1024, 0.999, approx=True)
+run("thresh 0.9", 32, 40, 1024, 0.9)
 run("stress: R=97 (tn~29.5k)", 32, 97, 1024, 0.99)
+run("stress: R=97, approximate mode", 32, 97, 1024, 0.99, approx=True)
 run("demo call site: b=1 hn=512", 1, 27, 512, 0.99)
 run("eval call site: b=1 hn=128 max_num=100", 1, 40, 128, 0.99, max_num=100)
 run_plan("demo call site: b=1 hn=512", 1, 27, 512, 0.99)
