@@ -309,6 +309,121 @@ __global__ void k_semantics_x(const float* __restrict__ a, const float* __restri
     out[i * 2] = acc;
     out[i * 2 + 1] = __builtin_bit_cast(unsigned, dm);
 }
+// EPI 10: y = clamp(min(a, b, 1)) in [0, 1] (the band shifted to (0, 1) by the operands: y = 0 a clean non-vote, y = 1 a clean vote);
+// two y per v_cvt_pk_fp8_f32 (four tests per dword: 0x00 / C = fp8(1.0) / something in between), votes S += bytes and band test
+// T += |byte - C/2| with one v_sad_u8 each per dword: a cell is clean iff T == tests * C/2 (every other byte is closer to C/2),
+// and then votes = S / C.  2.0 operations per test.
+__device__ __forceinline__ void ab_fp8(unsigned& S, unsigned& T, unsigned mid, AB_ARGS) {
+    float y0, y1, y2, y3;
+    unsigned w0, w1;
+    asm volatile(
+        "v_min3_f32 %2, %8, %9, 1.0 clamp\n"
+        "v_min3_f32 %3, %10, %11, 1.0 clamp\n"
+        "v_min3_f32 %4, %12, %13, 1.0 clamp\n"
+        "v_min3_f32 %5, %14, %15, 1.0 clamp\n"
+        "v_cvt_pk_fp8_f32 %6, %2, %3\n"
+        "v_cvt_pk_fp8_f32 %6, %4, %5 op_sel:[0,0,1]\n"
+        "v_min3_f32 %2, %16, %17, 1.0 clamp\n"
+        "v_min3_f32 %3, %18, %19, 1.0 clamp\n"
+        "v_min3_f32 %4, %20, %21, 1.0 clamp\n"
+        "v_min3_f32 %5, %22, %23, 1.0 clamp\n"
+        "v_sad_u8 %0, %6, 0, %0\n"
+        "v_cvt_pk_fp8_f32 %7, %2, %3\n"
+        "v_sad_u8 %1, %6, %24, %1\n"
+        "v_cvt_pk_fp8_f32 %7, %4, %5 op_sel:[0,0,1]\n"
+        "v_sad_u8 %0, %7, 0, %0\n"
+        "v_sad_u8 %1, %7, %24, %1\n"
+        : "+v"(S), "+v"(T), "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3), "=&v"(w0), "=&v"(w1)
+        : AB_IN, "s"(mid));
+}
+// EPI 11: the same with v_cvt_pk_bf8_f32 (e5m2)
+__device__ __forceinline__ void ab_bf8(unsigned& S, unsigned& T, unsigned mid, AB_ARGS) {
+    float y0, y1, y2, y3;
+    unsigned w0, w1;
+    asm volatile(
+        "v_min3_f32 %2, %8, %9, 1.0 clamp\n"
+        "v_min3_f32 %3, %10, %11, 1.0 clamp\n"
+        "v_min3_f32 %4, %12, %13, 1.0 clamp\n"
+        "v_min3_f32 %5, %14, %15, 1.0 clamp\n"
+        "v_cvt_pk_bf8_f32 %6, %2, %3\n"
+        "v_cvt_pk_bf8_f32 %6, %4, %5 op_sel:[0,0,1]\n"
+        "v_min3_f32 %2, %16, %17, 1.0 clamp\n"
+        "v_min3_f32 %3, %18, %19, 1.0 clamp\n"
+        "v_min3_f32 %4, %20, %21, 1.0 clamp\n"
+        "v_min3_f32 %5, %22, %23, 1.0 clamp\n"
+        "v_sad_u8 %0, %6, 0, %0\n"
+        "v_cvt_pk_bf8_f32 %7, %2, %3\n"
+        "v_sad_u8 %1, %6, %24, %1\n"
+        "v_cvt_pk_bf8_f32 %7, %4, %5 op_sel:[0,0,1]\n"
+        "v_sad_u8 %0, %7, 0, %0\n"
+        "v_sad_u8 %1, %7, %24, %1\n"
+        : "+v"(S), "+v"(T), "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3), "=&v"(w0), "=&v"(w1)
+        : AB_IN, "s"(mid));
+}
+// EPI 12: the conversions alone (1.5 operations: is v_cvt_pk_fp8_f32 full rate?)     EPI 13: min3-clamp + the SADs on the raw
+// float bits (1.5 operations: is v_sad_u8 full rate?)
+__device__ __forceinline__ void ab_fp8_only(unsigned& S, AB_ARGS) {
+    float y0, y1, y2, y3;
+    unsigned w0, w1;
+    asm volatile(
+        "v_min3_f32 %1, %7, %8, 1.0 clamp\n"
+        "v_min3_f32 %2, %9, %10, 1.0 clamp\n"
+        "v_min3_f32 %3, %11, %12, 1.0 clamp\n"
+        "v_min3_f32 %4, %13, %14, 1.0 clamp\n"
+        "v_cvt_pk_fp8_f32 %5, %1, %2\n"
+        "v_cvt_pk_fp8_f32 %5, %3, %4 op_sel:[0,0,1]\n"
+        "v_min3_f32 %1, %15, %16, 1.0 clamp\n"
+        "v_min3_f32 %2, %17, %18, 1.0 clamp\n"
+        "v_min3_f32 %3, %19, %20, 1.0 clamp\n"
+        "v_min3_f32 %4, %21, %22, 1.0 clamp\n"
+        "v_cvt_pk_fp8_f32 %6, %1, %2\n"
+        "v_cvt_pk_fp8_f32 %6, %3, %4 op_sel:[0,0,1]\n"
+        "v_xor_b32 %0, %0, %5\n"
+        "v_xor_b32 %0, %0, %6\n"
+        : "+v"(S), "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3), "=&v"(w0), "=&v"(w1)
+        : AB_IN);
+}
+__device__ __forceinline__ void ab_sad_only(unsigned& S, unsigned& T, unsigned mid, AB_ARGS) {
+    float y0, y1, y2, y3;
+    asm volatile(
+        "v_min3_f32 %2, %6, %7, 1.0 clamp\n"
+        "v_min3_f32 %3, %8, %9, 1.0 clamp\n"
+        "v_min3_f32 %4, %10, %11, 1.0 clamp\n"
+        "v_min3_f32 %5, %12, %13, 1.0 clamp\n"
+        "v_sad_u8 %0, %2, 0, %0\n"
+        "v_sad_u8 %1, %3, %22, %1\n"
+        "v_min3_f32 %2, %14, %15, 1.0 clamp\n"
+        "v_min3_f32 %3, %16, %17, 1.0 clamp\n"
+        "v_sad_u8 %0, %4, 0, %0\n"
+        "v_sad_u8 %1, %5, %22, %1\n"
+        "v_min3_f32 %4, %18, %19, 1.0 clamp\n"
+        "v_min3_f32 %5, %20, %21, 1.0 clamp\n"
+        : "+v"(S), "+v"(T), "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3)
+        : AB_IN, "s"(mid));
+}
+__global__ void k_semantics_fp8(const float* __restrict__ a, const float* __restrict__ b, unsigned* __restrict__ out, int bf8) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float av[8], bv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { av[q] = a[i * 8 + q]; bv[q] = b[i * 8 + q]; }
+    unsigned S = 0, T = 0;
+    const unsigned one = bf8 ? (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(1.0f, 1.0f, 0, false) & 0xFFu
+                             : (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(1.0f, 1.0f, 0, false) & 0xFFu;
+    const unsigned mid = __builtin_amdgcn_readfirstlane((one >> 1) * 0x01010101u);
+    if (bf8) ab_bf8(S, T, mid, av[0], bv[0], av[1], bv[1], av[2], bv[2], av[3], bv[3], av[4], bv[4], av[5], bv[5], av[6], bv[6], av[7], bv[7]);
+    else ab_fp8(S, T, mid, av[0], bv[0], av[1], bv[1], av[2], bv[2], av[3], bv[3], av[4], bv[4], av[5], bv[5], av[6], bv[6], av[7], bv[7]);
+    out[i * 4] = S;
+    out[i * 4 + 1] = T;
+    out[i * 4 + 2] = one;
+    // the codes of the first four tests, for the edge report
+    unsigned w = 0;
+    float y[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) y[q] = fminf(fmaxf(fminf(fminf(av[q], bv[q]), 1.0f), 0.f), 1.f);
+    if (bf8) { w = __builtin_amdgcn_cvt_pk_bf8_f32(y[0], y[1], w, false); w = __builtin_amdgcn_cvt_pk_bf8_f32(y[2], y[3], w, true); }
+    else { w = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], w, false); w = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], w, true); }
+    out[i * 4 + 3] = w;
+}
 #define AB_HALF(o) d[o + 0], cr[o + 0], d[o + 1], cr[o + 1], d[o + 2], cr[o + 2], d[o + 3], cr[o + 3], d[o + 4], cr[o + 4], \
                    d[o + 5], cr[o + 5], d[o + 6], cr[o + 6], d[o + 7], cr[o + 7]
 
@@ -375,6 +490,7 @@ __global__ __launch_bounds__(256) void k_pipe(const u16* __restrict__ Bsrc, cons
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const char* lbase = reinterpret_cast<const char*>(lds) + (lane & 31) * 32 + half * 16;
     const unsigned sel = 0x07050301u, ones8 = 0x01010101u, ones16 = 0x00010001u;
+    const unsigned mid8 = __builtin_amdgcn_readfirstlane(0x1C1C1C1Cu + (unsigned)(reps >> 30));
     for (int r = 0; r < reps; ++r) {
         bf16x8 Acr = *reinterpret_cast<const bf16x8*>(lbase), Ad = *reinterpret_cast<const bf16x8*>(lbase + 1024);
         f32x16 cr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Acr, B[0], zero, 0, 0, 0);
@@ -396,6 +512,10 @@ __global__ __launch_bounds__(256) void k_pipe(const u16* __restrict__ Bsrc, cons
                 else if (EPI == 6) ab_uclamp(s1[t], s2[t], AB_HALF(0));
                 else if (EPI == 7) ab_vote_only(s1[t], AB_HALF(0));
                 else if (EPI == 8) ab_min3_noabs(s1[t], f0[t], f1, f2, f3, AB_HALF(0));
+                else if (EPI == 10) ab_fp8(s1[t], s2[t], mid8, AB_HALF(0));
+                else if (EPI == 11) ab_bf8(s1[t], s2[t], mid8, AB_HALF(0));
+                else if (EPI == 12) ab_fp8_only(s1[t], AB_HALF(0));
+                else if (EPI == 13) ab_sad_only(s1[t], s2[t], mid8, AB_HALF(0));
                 else ab_x(s1[t], f0[t], AB_HALF(0));
                 __builtin_amdgcn_sched_barrier(0);
                 const f32x16 d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Ad : Nd, B[(t + 1) % MH], zero, 0, 0, 0);
@@ -409,6 +529,10 @@ __global__ __launch_bounds__(256) void k_pipe(const u16* __restrict__ Bsrc, cons
                 else if (EPI == 6) ab_uclamp(s1[t], s2[t], AB_HALF(8));
                 else if (EPI == 7) ab_vote_only(s1[t], AB_HALF(8));
                 else if (EPI == 8) ab_min3_noabs(s1[t], f0[t], f1, f2, f3, AB_HALF(8));
+                else if (EPI == 10) ab_fp8(s1[t], s2[t], mid8, AB_HALF(8));
+                else if (EPI == 11) ab_bf8(s1[t], s2[t], mid8, AB_HALF(8));
+                else if (EPI == 12) ab_fp8_only(s1[t], AB_HALF(8));
+                else if (EPI == 13) ab_sad_only(s1[t], s2[t], mid8, AB_HALF(8));
                 else ab_x(s1[t], f0[t], AB_HALF(8));
                 __builtin_amdgcn_sched_barrier(0);
                 cr = cr2;
@@ -525,6 +649,63 @@ int main() {
         }
         printf("x-epilogue semantics: %d cells of 8 tests, %ld clean; wrong band flags %ld, wrong vote decodes in clean cells %ld\n", n, clean, wrong_band, wrong_votes);
     }
+    // ---- 1c. the fp8 / bf8 + SAD epilogue
+    for (int bf8 = 0; bf8 < 2; ++bf8) {
+        const int n = 64 * 256;
+        std::vector<float> a(n * 8), b(n * 8);
+        for (int i = 0; i < n; ++i) {
+            const int cellkind = rand() % 4;  // 0: all clean, else: some tests inside (0, 1)
+            for (int q = 0; q < 8; ++q) {
+                float lo;
+                const int kind = cellkind == 0 ? rand() % 2 : rand() % 8;
+                if (kind == 0) lo = -rnd() * 50.f;                       // clean non-vote (y = 0)
+                else if (kind == 1) lo = 1.f + rnd() * 50.f;             // clean vote (y = 1)
+                else if (kind == 2) lo = rnd();                          // anywhere in (0, 1)
+                else if (kind == 3) lo = ldexpf(1.f, -(rand() % 20));    // small powers of two
+                else if (kind == 4) lo = 1.f - ldexpf(1.f, -(rand() % 20));  // just below 1
+                else if (kind == 5) lo = 0.05f + 0.9f * rnd();           // the band proper
+                else if (kind == 6) lo = rand() & 1 ? 0.05f : 0.95f;     // its two ends
+                else lo = 0.f;
+                const float hi = lo + rnd() * 3.f;
+                if (rand() & 1) { a[i * 8 + q] = lo; b[i * 8 + q] = hi; } else { a[i * 8 + q] = hi; b[i * 8 + q] = lo; }
+            }
+        }
+        float *da, *db; unsigned* dout;
+        hipMalloc(&da, n * 32); hipMalloc(&db, n * 32); hipMalloc(&dout, n * 16);
+        hipMemcpy(da, a.data(), n * 32, hipMemcpyHostToDevice);
+        hipMemcpy(db, b.data(), n * 32, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_semantics_fp8, dim3(n / 64), dim3(64), 0, 0, da, db, dout, bf8);
+        std::vector<unsigned> out(n * 4);
+        hipMemcpy(out.data(), dout, n * 16, hipMemcpyDeviceToHost);
+        const unsigned one = out[2];
+        long clean_true = 0, flagged = 0, missed_band = 0, wrong_votes = 0, edge_to_0 = 0, edge_to_1 = 0, nonmono = 0;
+        float max_to_0 = 0.f, min_to_1 = 1.f;
+        for (int i = 0; i < n; ++i) {
+            int votes = 0; bool all_clean = true, has_band = false;
+            for (int q = 0; q < 8; ++q) {
+                const float m = fminf(a[i * 8 + q], b[i * 8 + q]);
+                const float y = m < 0.f ? 0.f : (m > 1.f ? 1.f : m);
+                if (y == 1.f) ++votes;
+                if (y != 0.f && y != 1.f) all_clean = false;
+                if (y >= 0.05f && y <= 0.95f) has_band = true;
+                if (q < 4) {
+                    const unsigned code = (out[i * 4 + 3] >> (8 * q)) & 0xFFu;
+                    if (code > one) ++nonmono;
+                    if (y > 0.f && y < 1.f && code == 0) { ++edge_to_0; if (y > max_to_0) max_to_0 = y; }
+                    if (y > 0.f && y < 1.f && code == one) { ++edge_to_1; if (y < min_to_1) min_to_1 = y; }
+                }
+            }
+            const unsigned S = out[i * 4], T = out[i * 4 + 1];
+            const bool looks_clean = T == 8 * (one >> 1);
+            if (all_clean) ++clean_true;
+            if (!looks_clean) ++flagged;
+            if (has_band && looks_clean) ++missed_band;
+            if (all_clean && (!looks_clean || S != one * (unsigned)votes)) ++wrong_votes;
+        }
+        printf("%s + sad semantics: code(1.0) = 0x%02x; %d cells of 8 tests, %ld truly clean, %ld flagged; cells with a test in [0.05, 0.95] NOT flagged: %ld; "
+               "clean cells with wrong flag / votes: %ld; codes above code(1.0): %ld; y in (0,1) coded 0: %ld (largest %.3g), coded 1.0: %ld (smallest %.6f)\n",
+               bf8 ? "bf8" : "fp8", one, n, clean_true, flagged, missed_band, wrong_votes, nonmono, edge_to_0, max_to_0, edge_to_1, min_to_1);
+    }
     // ---- 2. MFMA accumulation error
     {
         const int nb = 4096;
@@ -576,12 +757,12 @@ int main() {
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
         for (int wpc = 3; wpc <= 3; ++wpc)
-            for (int epi = 0; epi < 10; ++epi) {
+            for (int epi = 0; epi < 14; ++epi) {
                 const dim3 g(cus * wpc), b(256);
                 const int reps = 64;
                 auto launch = [&] {
 #define LAUNCH(E) case E: hipLaunchKernelGGL((k_pipe<MH, E>), g, b, ntiles * TILE_BYTES, 0, dB, dA, dc, ntiles, reps); break;
-                    switch (epi) { LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) LAUNCH(9) }
+                    switch (epi) { LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) LAUNCH(9) LAUNCH(10) LAUNCH(11) LAUNCH(12) LAUNCH(13) }
 #undef LAUNCH
                 };
                 launch();
@@ -603,6 +784,10 @@ int main() {
                        epi == 4 ? "a/b: min-clamp, min3 x4 chains, add3 (2.5)" : epi == 5 ? "a/b: min-clamp, 2 x min |.|, add3  (3.5)" :
                        epi == 6 ? "a/b: min-clamp, min|.|-clamp, 2 add3 (3.0)" : epi == 7 ? "a/b: min-clamp + add3 only        (1.5)" :
                        epi == 8 ? "a/b: min3 without |.|, 4 chains    (2.5)" :
+                       epi == 10 ? "a/b: y = clamp min3, cvt_pk_fp8, 2 x sad_u8 (2.0)" :
+                       epi == 11 ? "a/b: y = clamp min3, cvt_pk_bf8, 2 x sad_u8 (2.0)" :
+                       epi == 12 ? "a/b: y = clamp min3, cvt_pk_fp8 only       (1.5+)" :
+                       epi == 13 ? "a/b: y = clamp min3, sad_u8 on raw bits    (1.5)" :
                                   "a/b: x = min3(a, b, 1), min3 |x|, cvt_pknorm, add3 (2.25)",
                        best, tests / best / 1e9);
             }
