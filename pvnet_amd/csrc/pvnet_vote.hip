@@ -224,10 +224,14 @@ __device__ __forceinline__ float vote_expanded(float4 a, float2 b, float hx, flo
 // An fp32 value is the exact sum of three bf16 parts (round-to-nearest each time).  A product x*a keeps the six
 // part pairs of relative weight >= 2^-16 (x0a0 x0a1 x1a0 x0a2 x2a0 x1a1; the dropped three are below one fp32
 // rounding of the product), so the 3-term dot products of the vote, cr = hx*a + hy*b + c and dt = hx*e + hy*f + g,
-// are ONE v_mfma_f32_32x32x16_bf16 each (K = 6 + 6 + 3, one slot spare), accumulated in fp32 by the matrix pipe:
-//   A row (pixel)      k = 0..15 : a0 a1 a0 a2 a0 a1 | b0 b1 b0 b2 b0 b1 | c0 c1 c2 0
-//   B column (hyp.)    k = 0..15 : x0 x0 x1 x0 x2 x1 | y0 y0 y1 y0 y2 y1 | 1  1  1  0
+// are ONE v_mfma_f32_32x32x16_bf16 each (K = 6 + 6 + 3, one slot spare), accumulated in fp32 by the matrix pipe.
+// The K order is free as long as both operands agree; it is chosen so that every dword of a row holds the SAME part of
+// the two coefficients -- one v_cvt_pk_bf16_f32 makes it (round 3; the former order needed a pack per dword):
+//   A row (pixel)      k = 0..15 : a0 b0 | a1 b1 | a0 b0 | a2 b2 | a0 b0 | a1 b1 | c0 c1 | c2 spare
+//   B column (hyp.)    k = 0..15 : x0 y0 | x0 y0 | x1 y1 | x0 y0 | x2 y2 | x1 y1 | 1  1  | 1  spare
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ void split3(float x, uint32_t& p0, uint32_t& p1, uint32_t& p2) {  // raw bf16 bits
@@ -241,23 +245,33 @@ __device__ __forceinline__ void split3(float x, uint32_t& p0, uint32_t& p1, uint
     p2 = __builtin_bit_cast(unsigned short, h2);
 }
 __device__ __forceinline__ uint32_t pk(uint32_t lo, uint32_t hi) { return lo | (hi << 16); }
-// the 16 K-slots of one operand row: (u, v, w) -> u0 u1 u0 u2 u0 u1 | v0 v1 v0 v2 v0 v1 | w0 w1 w2 0
-__device__ __forceinline__ void a_row(float u, float v, float w, uint4& lo, uint4& hi) {
-    uint32_t u0, u1, u2, v0, v1, v2, w0, w1, w2;
-    split3(u, u0, u1, u2);
-    split3(v, v0, v1, v2);
-    split3(w, w0, w1, w2);
-    lo = make_uint4(pk(u0, u1), pk(u0, u2), pk(u0, u1), pk(v0, v1));
-    hi = make_uint4(pk(v0, v2), pk(v0, v1), pk(w0, w1), pk(w2, 0u));
+// (bf16(a) | bf16(b) << 16), both rounded to nearest even: v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
-// the hypothesis side: (x, y) -> x0 x0 x1 x0 x2 x1 | y0 y0 y1 y0 y2 y1 | 1 1 1 0
+// the three parts of two values, pairwise packed: q0 = (a0 | b0), q1 = (a1 | b1), q2 = (a2 | b2)
+__device__ __forceinline__ void split3_pair(float a, float b, uint32_t& q0, uint32_t& q1, uint32_t& q2) {
+    q0 = pk_bf16(a, b);
+    const float ra = a - __uint_as_float(q0 << 16), rb = b - __uint_as_float(q0 & 0xFFFF0000u);   // exact
+    q1 = pk_bf16(ra, rb);
+    q2 = pk_bf16(ra - __uint_as_float(q1 << 16), rb - __uint_as_float(q1 & 0xFFFF0000u));
+}
+// the 16 K-slots of one operand row: (u, v, w) -> u0 v0 | u1 v1 | u0 v0 | u2 v2 | u0 v0 | u1 v1 | w0 w1 | w2 0
+__device__ __forceinline__ void a_row(float u, float v, float w, uint4& lo, uint4& hi) {
+    uint32_t q0, q1, q2, w0, w1, w2;
+    split3_pair(u, v, q0, q1, q2);
+    split3(w, w0, w1, w2);
+    lo = make_uint4(q0, q1, q0, q2);
+    hi = make_uint4(q0, q1, pk(w0, w1), pk(w2, 0u));
+}
+// the hypothesis side: (x, y) -> x0 y0 | x0 y0 | x1 y1 | x0 y0 | x2 y2 | x1 y1 | 1 1 | 1 0
 __device__ __forceinline__ void b_col(float x, float y, uint4& lo, uint4& hi) {
-    uint32_t x0, x1, x2, y0, y1, y2;
-    split3(x, x0, x1, x2);
-    split3(y, y0, y1, y2);
+    uint32_t q0, q1, q2;
+    split3_pair(x, y, q0, q1, q2);
     const uint32_t one = 0x3F80u;
-    lo = make_uint4(pk(x0, x0), pk(x1, x0), pk(x2, x1), pk(y0, y0));
-    hi = make_uint4(pk(y1, y0), pk(y2, y1), pk(one, one), pk(one, 0u));
+    lo = make_uint4(q0, q0, q1, q0);
+    hi = make_uint4(q2, q1, pk(one, one), pk(one, 0u));
 }
 
 // ---- exact mode: the same two MFMAs, arranged so that the epilogue also sees how close every test is to the threshold
@@ -305,12 +319,11 @@ __device__ __forceinline__ void b_col_exact(float hxo, float hyo, float rho, flo
         hi = make_uint4(0u, 0u, 0u, pk(0u, one));
         return;
     }
-    uint32_t x0, x1, x2, y0, y1, y2;
-    split3(hxo * s, x0, x1, x2);
-    split3(hyo * s, y0, y1, y2);
+    uint32_t q0, q1, q2;
+    split3_pair(hxo * s, hyo * s, q0, q1, q2);
     const uint32_t sb = __float_as_uint(s) >> 16;
-    lo = make_uint4(pk(x0, x0), pk(x1, x0), pk(x2, x1), pk(y0, y0));
-    hi = make_uint4(pk(y1, y0), pk(y2, y1), pk(sb, sb), pk(sb, one));
+    lo = make_uint4(q0, q0, q1, q0);
+    hi = make_uint4(q2, q1, pk(sb, sb), pk(sb, one));
 }
 // per-pixel rows of a = dt - cr and b = dt + cr, the direction normalised to |M| = sigma <= rho / (rho + r)
 __device__ __forceinline__ void a_rows_exact(float4 q, float tau, float ox, float oy, float rho, uint4& alo, uint4& ahi,
@@ -925,6 +938,13 @@ __device__ __forceinline__ int half_wave_sum(int v) {
     const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
     return (int)(r[0] + r[1]);
 }
+// two hypothesis tiles at once: returns (a + a's other half-wave) in lanes 0..31 and (b + b's other half-wave) in lanes 32..63 --
+// one swap and one add for two columns sets, and the decode / atomic that follow run on 64 useful lanes instead of 32.
+// Works on the WRAPPED accumulators (their encodings are linear mod 2^32).
+__device__ __forceinline__ unsigned half_wave_sum2(unsigned a, unsigned b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);  // r[0] = (a.lo | b.lo), r[1] = (a.hi | b.hi)
+    return r[0] + r[1];
+}
 constexpr int VOTE_WRAP = 512;  // vote8 accumulators hold their count mod 512
 __device__ __forceinline__ int votes_of(unsigned acc) { return (int)(((acc >> 23) * 383u) & 511u); }
 
@@ -1012,14 +1032,22 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
         }
         // the group's counts: atomic adds into counts[] (default), or one uint16 row per chunk GROUP for K5 to sum
         uint16_t* po = P.partial + (bk * P.max_chunks + cg) * P.hn_pad + h0;
+        if (MH >= 2 && P.atomic_counts) {  // tiles in pairs: lanes 0..31 finish tile t, lanes 32..63 tile t + 1
 #pragma unroll
-        for (int t = 0; t < MH; ++t) {
-            const int ci = votes_of(cnt[t]);
-            const int c = half_wave_sum(ci);  // the half-waves hold different rows of the column
-            if (P.atomic_counts) {
-                if (half == 0 && c > 0) atomicAdd(P.counts + bk * P.hn_pad + h0 + t * 32 + col, c);
-            } else if (half == 0) {
-                po[t * 32 + col] = (uint16_t)c;
+            for (int t = 0; t + 1 < MH; t += 2) {
+                const int c = votes_of(half_wave_sum2(cnt[t], cnt[t + 1]));
+                if (c > 0) atomicAdd(P.counts + bk * P.hn_pad + h0 + t * 32 + lane, c);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < MH; ++t) {
+                const int ci = votes_of(cnt[t]);
+                const int c = half_wave_sum(ci);  // the half-waves hold different rows of the column
+                if (P.atomic_counts) {
+                    if (half == 0 && c > 0) atomicAdd(P.counts + bk * P.hn_pad + h0 + t * 32 + col, c);
+                } else if (half == 0) {
+                    po[t * 32 + col] = (uint16_t)c;
+                }
             }
         }
     }
@@ -1256,21 +1284,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         int colx = col;  // opaque copy: keeps the eight per-tile addresses below from being hoisted above the scoring loop,
         asm volatile("" : "+v"(colx));  // where they would cost 20 VGPRs at the point of highest pressure
         int32_t* const pcnt = P.counts + bk * P.hn_pad + h0;
+        const bool padded = h0 + MH * 32 > P.hn;  // wave-uniform: only the last slice can hold padding columns
+        if (!FOLD) {
+#pragma unroll
+            for (int t = 0; t < MH; ++t) cnt[t] = dmn[t] >= BAND_CLEAN ? cnt[t] : 0u;  // a flagged cell's votes are discarded
+        }
+        if (MH >= 2) {  // the clean cells' votes, tiles in pairs: lanes 0..31 finish tile t, lanes 32..63 tile t + 1
+            int lanex = lane;
+            asm volatile("" : "+v"(lanex));
+#pragma unroll
+            for (int t = 0; t + 1 < MH; t += 2) {
+                const int c = votes_of_norm(half_wave_sum2(cnt[t], cnt[t + 1]));
+                if (c > 0) atomicAdd(pcnt + t * 32 + lanex, c);
+            }
+        } else {
+            const int c = votes_of_norm(half_wave_sum2(cnt[0], cnt[0]));
+            if (half == 0 && c > 0) atomicAdd(pcnt + colx, c);
+        }
 #pragma unroll
         for (int t = 0; t < MH; ++t) {
-            unsigned mask;
-            int votes;
-            if (FOLD) {
-                votes = votes_of_norm(cnt[t]);
-                mask = flg[t];
-            } else {
-                const bool bad = !(dmn[t] >= BAND_CLEAN);
-                votes = bad ? 0 : votes_of_norm(cnt[t]);
-                mask = bad ? all_groups : 0u;
-            }
-            const int c = half_wave_sum(votes);  // the half-waves hold different rows of the column
-            if (half == 0 && c > 0) atomicAdd(pcnt + t * 32 + colx, c);
-            if (h0 + t * 32 + colx >= P.hn) mask = 0u;  // padding columns of the last slice: nobody reads their counts
+            unsigned mask = FOLD ? flg[t] : (dmn[t] >= BAND_CLEAN ? 0u : all_groups);
+            if (padded && h0 + t * 32 + colx >= P.hn) mask = 0u;  // padding columns of the last slice: nobody reads their counts
             const unsigned long long bal = __ballot(mask != 0u);
             if (bal) {  // wave-uniform
                 int base = 0;
