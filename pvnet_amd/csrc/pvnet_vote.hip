@@ -337,7 +337,12 @@ __device__ __forceinline__ void a_rows_exact(float4 q, float tau, float ox, floa
     // the gate's own arithmetic (norm1_literal), which only directions within a factor two of the gate need: records keep
     // the RAW direction in exact mode, as hypothesis generation needs it
     bool dead = !(m > 0.f) || !finite;
-    if (!dead && m <= 2.0e-6f) dead = norm1_literal(q.z, q.w) <= kF1e6;  // (m > 2e-6 implies norm1 > 1e-6 in any rounding)
+    const bool near_gate = !dead && m <= 2.0e-6f;  // (m > 2e-6 implies norm1 > 1e-6 in any rounding)
+    if (__ballot(near_gate)) {  // wave-uniform and almost never taken; the empty asm keeps the correctly-rounded sqrt (~25
+        float nz = q.z;         // instructions) from being speculated out of the branch, where every pixel would pay for it
+        asm volatile("" : "+v"(nz));
+        if (near_gate) dead = norm1_literal(nz, q.w) <= kF1e6;
+    }
     if (dead) {
         ahi.w = bhi.w = pk(0u, never);
         return;
@@ -1227,7 +1232,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             if (p < tpad) q = P.rec[bk * P.cap + p];
             s_raw[i] = q;
             uint4* t = s_t + (i >> 5) * TILE_U4 + (i & 31) * 2;
-            a_rows_exact(q, P.tau, ox, oy, rho, t[0], t[1], t[64], t[65]);
+            uint4 r0, r1, r2, r3;  // (in registers first: by reference into LDS every assignment inside would be a store)
+            a_rows_exact(q, P.tau, ox, oy, rho, r0, r1, r2, r3);
+            t[0] = r0;
+            t[1] = r1;
+            t[64] = r2;
+            t[65] = r3;
         }
 #pragma unroll
         for (int j = 0; j < (4 * MH * 32 + 255) / 256; ++j)
