@@ -1,7 +1,7 @@
 """Development aid: energy per batch of the voting path and of its parts.  For each variant a loop of calls runs for a
 few seconds on S streams while a sampler thread reads `rocm-smi --showpower --showclocks`; the table gives the step time,
 the mean package power and clock, and their product = energy per batch.
-    python tools/energy_probe.py [streams]
+    python tools/energy_probe.py [streams] [--approx]        (default: the library's default = exact mode)
 Variants (PVNET_DEV_STAGES masks on workspaces that complete calls left behind): all six stages, the scoring kernel alone,
 the five small stages alone; then all stages on ONE stream."""
 import os
@@ -16,7 +16,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pvnet_amd import synth, voting  # noqa: E402
 
-S = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+APPROX = "--approx" in sys.argv
+_pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+S = int(_pos[0]) if _pos else 6
 SECONDS = float(os.environ.get("PROBE_SECONDS", 5))
 dev = torch.device("cuda:0")
 sets = []
@@ -47,7 +49,7 @@ def variant(name, stages, ns):
         for i in range(i0, i0 + n):
             m, v = sets[i % 2]
             with torch.cuda.stream(streams[i % ns]):
-                voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=i % 64, workspace=ws[i % ns])
+                voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=i % 64, workspace=ws[i % ns], approx=APPROX)
         torch.cuda.synchronize()
 
     os.environ["PVNET_DEV_STAGES"] = str(0x3F)
@@ -78,6 +80,7 @@ def variant(name, stages, ns):
 
 
 idle = subprocess.run(["rocm-smi", "--showpower"], capture_output=True, text=True).stdout
+print("mode:", "approx" if APPROX else "exact")
 print("idle:", " ".join(re.findall(r"Power \(W\): [0-9.]+", idle)))
 variant("all six stages", 0x3F, S)
 variant("scoring kernel alone", 0x10, S)
