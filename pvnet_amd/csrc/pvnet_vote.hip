@@ -1181,9 +1181,17 @@ constexpr float BAND_CLEAN = 1.0f;     // a cell whose minimum |a'|, |b'| reache
 //           (cheapest epilogue; right when flagged cells are very rare: loose thresholds, band_fold());
 // FOLD = 1: one cell per (lane, hypothesis tile, PIXEL tile) -- the test is made after every step (four more VALU operations,
 //           vote8x_open / vote8x_close), and a flagged cell costs 16 literal tests instead of 16 * tiles.
-template <int MH, int FOLD, bool TIMED>
+// NACC = 2: two accumulator pairs -- the MFMAs of step i + 1 are issued around the votes of step i (the flat pipeline of the
+//           approximate kernel);
+// NACC = 1: one pair -- a wave issues the step's two MFMAs and consumes their results right away, the SIMD's other waves
+//           fill the wait.  tools/ubench_exact.hip: 13.48 against 13.67 T tests/s at 3 waves per SIMD -- and 32 VGPRs fewer,
+//           which other streams' small stages can use while this kernel is resident (PVNET_SCORE_ACC).
+template <int MH, int FOLD, bool TIMED, int NACC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void score_exact_kernel(VoteParams P) {
-    if (MH == 8) PVNET_SPARE_VGPRS(167); else if (MH == 4) PVNET_SPARE_VGPRS(143); else PVNET_SPARE_VGPRS(111);
+    if (MH == 8 && NACC == 2) PVNET_SPARE_VGPRS(167);
+    else if (MH == 8) PVNET_SPARE_VGPRS(135);
+    else if (MH == 4) PVNET_SPARE_VGPRS(143);
+    else PVNET_SPARE_VGPRS(111);
     unsigned long long* __restrict__ stamps = reinterpret_cast<unsigned long long*>(P.pix);
     if (TIMED && threadIdx.x == 0) stamps[2 * blockIdx.x] = (unsigned long long)wall_clock64();
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1252,11 +1260,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             cnt[t] = flg[t] = 0u;
             dmn[t] = 3.0e38f;
         }
-        bf16x8 Aa = __builtin_bit_cast(bf16x8, lbase[0]), Ab = __builtin_bit_cast(bf16x8, lbase[64]);
-        f32x16 va = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aa, B[0], zero, 0, 0, 0);
-        f32x16 vb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ab, B[0], zero, 0, 0, 0);
         const int left = (tpad - cg * npx + 31) >> 5;
         const int nti = left < ntiles ? left : ntiles;
+        bf16x8 Aa = __builtin_bit_cast(bf16x8, lbase[0]), Ab = __builtin_bit_cast(bf16x8, lbase[64]);
+        if (NACC == 1) {
+            for (int tile = 0; tile < nti; ++tile) {
+                const int nt = tile + 1 < nti ? tile + 1 : tile;
+                const bf16x8 Na = __builtin_bit_cast(bf16x8, lbase[nt * TILE_U4]);
+                const bf16x8 Nb = __builtin_bit_cast(bf16x8, lbase[nt * TILE_U4 + 64]);
+#pragma unroll
+                for (int t = 0; t < MH; ++t) {
+                    unsigned acc = 0u;
+                    float dmo = 0.f;
+                    const f32x16 va = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aa, B[t], zero, 0, 0, 0);
+                    const f32x16 vb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ab, B[t], zero, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_nop 11");    // the votes are inline asm: the compiler does not see an MFMA result being read,
+                    __builtin_amdgcn_sched_barrier(0);  // so the wait states are ours to insert (tools/check_mfma_hazard.py)
+                    if (FOLD) {
+                        vote8x_open(acc, dmo, va[0], vb[0], va[1], vb[1], va[2], vb[2], va[3], vb[3], va[4], vb[4], va[5], vb[5],
+                                    va[6], vb[6], va[7], vb[7]);
+                        vote8x_close(cnt[t], flg[t], acc, dmo, va[8], vb[8], va[9], vb[9], va[10], vb[10], va[11], vb[11], va[12],
+                                     vb[12], va[13], vb[13], va[14], vb[14], va[15], vb[15]);
+                    } else {
+                        vote8x(cnt[t], dmn[t], va[0], vb[0], va[1], vb[1], va[2], vb[2], va[3], vb[3], va[4], vb[4], va[5], vb[5],
+                               va[6], vb[6], va[7], vb[7]);
+                        vote8x(cnt[t], dmn[t], va[8], vb[8], va[9], vb[9], va[10], vb[10], va[11], vb[11], va[12], vb[12], va[13],
+                               vb[13], va[14], vb[14], va[15], vb[15]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                Aa = Na;
+                Ab = Nb;
+            }
+        } else {
+        f32x16 va = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aa, B[0], zero, 0, 0, 0);
+        f32x16 vb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ab, B[0], zero, 0, 0, 0);
         for (int tile = 0; tile < nti; ++tile) {
             const int nt = tile + 1 < nti ? tile + 1 : tile;
             const bf16x8 Na = __builtin_bit_cast(bf16x8, lbase[nt * TILE_U4]);
@@ -1288,6 +1327,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             }
             Aa = Na;
             Ab = Nb;
+        }
         }
         // ---- clean cells: their counts; flagged cells: into the item's list
         const unsigned all_groups = 1u;  // FOLD = 0: the one cell of the item
@@ -1398,7 +1438,8 @@ constexpr int RT = PVNET_RT;  // threads per (image, key-point) (measured: 256 -
 constexpr int RW = RT / 64;
 template <bool LITERAL>
 __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
-    PVNET_SPARE_VGPRS(111);
+    PVNET_SPARE_VGPRS(71);  // (62 used.  Round 3: was 111 -- with 112 registers a workgroup of 8 waves needs 224 per SIMD and starts late in
+                            //  the tail of another batch's scoring launch; 72: +3 % with six batches in flight)
     small_stage_prio();
     const int k = blockIdx.x, bi = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1882,6 +1923,8 @@ struct Tuning {
                         //                         for other streams' small stages; 0 = no padding
     int score_atomic;   // PVNET_SCORE_ATOMIC      1 (default): K4 adds its counts into `counts` with integer atomics;
                         //                         0: per-chunk uint16 count rows (`partial`) summed by K5
+    int score_acc;      // PVNET_SCORE_ACC         exact mode, 8 tiles per wave: accumulator pairs of the scoring loop (2: MFMAs of the
+                        //                         next step issued around this step's votes; 1: one pair, 32 VGPRs fewer)
     int exact_fold;     // PVNET_EXACT_FOLD        exact mode: -1 (default) = by threshold, 0 = one cell per work item and
                         //                         hypothesis, 1 = one cell per pixel tile (band_fold1())
     int dev_stages;     // PVNET_DEV_STAGES        development aid: bit mask of the stages to launch
@@ -1896,6 +1939,7 @@ void load_tuning(Tuning& t) {
     t.score_xcd = env_int("PVNET_SCORE_XCD", 1);
     t.score_atomic = env_int("PVNET_SCORE_ATOMIC", 1);
     t.score_lds_kb = env_int("PVNET_SCORE_LDS_KB", 0);
+    t.score_acc = env_int("PVNET_SCORE_ACC", 2);
     t.exact_fold = env_int("PVNET_EXACT_FOLD", -1);
     t.dev_stages = env_int("PVNET_DEV_STAGES", 0x3F);
     int dev = 0, n = 0;
@@ -2007,21 +2051,21 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
             if (T.score_lds_kb > 0 && T.score_lds_kb <= 64 && lds < (size_t)T.score_lds_kb * 1024) lds = (size_t)T.score_lds_kb * 1024;
             const dim3 g((unsigned)wgs), t(256);
             const int fold = P.fold1;
-#define PV_EXACT(MH_)                                                                                               \
+#define PV_EXACT(MH_, NACC_)                                                                                        \
     do {                                                                                                            \
         if (timed_score) {                                                                                          \
-            if (fold == 1) hipLaunchKernelGGL((score_exact_kernel<MH_, 1, true>), g, t, lds, s, P);                 \
-            else hipLaunchKernelGGL((score_exact_kernel<MH_, 0, true>), g, t, lds, s, P);                           \
+            if (fold == 1) hipLaunchKernelGGL((score_exact_kernel<MH_, 1, true, NACC_>), g, t, lds, s, P);          \
+            else hipLaunchKernelGGL((score_exact_kernel<MH_, 0, true, NACC_>), g, t, lds, s, P);                    \
         } else {                                                                                                    \
-            if (fold == 1) hipLaunchKernelGGL((score_exact_kernel<MH_, 1, false>), g, t, lds, s, P);                \
-            else hipLaunchKernelGGL((score_exact_kernel<MH_, 0, false>), g, t, lds, s, P);                          \
+            if (fold == 1) hipLaunchKernelGGL((score_exact_kernel<MH_, 1, false, NACC_>), g, t, lds, s, P);         \
+            else hipLaunchKernelGGL((score_exact_kernel<MH_, 0, false, NACC_>), g, t, lds, s, P);                   \
         }                                                                                                           \
     } while (0)
             switch (mh) {
-                case 1: PV_EXACT(1); break;
-                case 2: PV_EXACT(2); break;
-                case 4: PV_EXACT(4); break;
-                case 8: PV_EXACT(8); break;
+                case 1: PV_EXACT(1, 2); break;
+                case 2: PV_EXACT(2, 2); break;
+                case 4: PV_EXACT(4, 2); break;
+                case 8: if (T.score_acc == 1) PV_EXACT(8, 1); else PV_EXACT(8, 2); break;
                 default: return PVNET_E_UNSUPPORTED;
             }
 #undef PV_EXACT

@@ -82,6 +82,14 @@ def variant(name, stages, ns):
 idle = subprocess.run(["rocm-smi", "--showpower"], capture_output=True, text=True).stdout
 print("mode:", "approx" if APPROX else "exact")
 print("idle:", " ".join(re.findall(r"Power \(W\): [0-9.]+", idle)))
+if "--each" in sys.argv:  # every small stage on its own (what does each cost when S batches keep it busy?)
+    for nm, bits in (("K1 mask bits alone", 0x01), ("K2 compaction alone", 0x04), ("K3 hypotheses + plan alone", 0x08),
+                     ("K5 select / refine alone", 0x20), ("K1 + K2", 0x05), ("K3 + K5", 0x28), ("five small stages", 0x2F)):
+        variant(nm, bits, S)
+    for nm, bits in (("K1 mask bits alone", 0x01), ("K2 compaction alone", 0x04), ("K3 hypotheses + plan alone", 0x08),
+                     ("K5 select / refine alone", 0x20)):
+        variant(nm, bits, 1)
+    sys.exit(0)
 variant("all six stages", 0x3F, S)
 variant("scoring kernel alone", 0x10, S)
 variant("five small stages alone", 0x2F, S)

@@ -548,6 +548,50 @@ __global__ __launch_bounds__(256) void k_pipe(const u16* __restrict__ Bsrc, cons
             s1[t] ^ s2[t] ^ __builtin_bit_cast(unsigned, f0[t]) ^ __builtin_bit_cast(unsigned, f1 + f2 + f3);
 }
 
+// PIPE 1: the same work with ONE accumulator pair -- the two MFMAs of a step are issued and their 32 results consumed by the
+// same wave right away (the wave waits for the matrix pipe; the SIMD's other waves fill the gap).  32 VGPRs fewer.
+template <int MH, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_pipe1(
+    const u16* __restrict__ Bsrc, const u16* __restrict__ Asrc, unsigned* __restrict__ counts, int ntiles, int reps) {
+    extern __shared__ __attribute__((aligned(16))) u16 lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    for (int i = threadIdx.x; i < ntiles * TILE_BYTES / 2; i += 256) lds[i] = Asrc[i];
+    bf16x8 B[MH];
+    unsigned s1[MH];
+    float f0[MH];
+#pragma unroll
+    for (int t = 0; t < MH; ++t) {
+        const int j = (wave * MH + t) * 32 + (lane & 31);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) B[t][k] = __builtin_bit_cast(__bf16, Bsrc[j * 16 + half * 8 + k]);
+        s1[t] = 0u;
+        f0[t] = 3e38f;
+    }
+    __syncthreads();
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const char* lbase = reinterpret_cast<const char*>(lds) + (lane & 31) * 32 + half * 16;
+    for (int r = 0; r < reps; ++r) {
+        for (int tile = 0; tile < ntiles; ++tile) {
+            const bf16x8 Acr = *reinterpret_cast<const bf16x8*>(lbase + tile * TILE_BYTES);
+            const bf16x8 Ad = *reinterpret_cast<const bf16x8*>(lbase + tile * TILE_BYTES + 1024);
+#pragma unroll
+            for (int t = 0; t < MH; ++t) {
+                const f32x16 cr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Acr, B[t], zero, 0, 0, 0);
+                const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ad, B[t], zero, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 11");  // MFMA result -> inline-asm VALU read: the wait states are ours to insert
+                __builtin_amdgcn_sched_barrier(0);
+                ab_x(s1[t], f0[t], AB_HALF(0));
+                ab_x(s1[t], f0[t], AB_HALF(8));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MH; ++t)
+        counts[(((size_t)blockIdx.x * 4 + wave) * MH + t) * 64 + lane] = s1[t] ^ __builtin_bit_cast(unsigned, f0[t]);
+}
+
 static float h2f(unsigned short h) { _Float16 x = __builtin_bit_cast(_Float16, h); return (float)x; }
 
 int main() {
@@ -791,6 +835,50 @@ int main() {
                                   "a/b: x = min3(a, b, 1), min3 |x|, cvt_pknorm, add3 (2.25)",
                        best, tests / best / 1e9);
             }
+    }
+    // ---- 4. one accumulator pair instead of two (PIPE 1), 3 and 4 workgroups per CU
+    {
+        constexpr int MH = 8;
+        const int ntiles = 8;
+        std::vector<u16> Bs(4 * MH * 32 * 16), As(ntiles * TILE_BYTES / 2);
+        for (auto& x : Bs) x = bf16_rn((rnd() - .5f) * 64.f);
+        for (auto& x : As) x = bf16_rn((rnd() - .5f) * 4.f);
+        u16 *dB, *dA; unsigned* dc;
+        hipMalloc(&dB, Bs.size() * 2); hipMalloc(&dA, As.size() * 2); hipMalloc(&dc, (size_t)cus * 8 * 4 * MH * 64 * 4);
+        hipMemcpy(dB, Bs.data(), Bs.size() * 2, hipMemcpyHostToDevice);
+        hipMemcpy(dA, As.data(), As.size() * 2, hipMemcpyHostToDevice);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int var = 0; var < 3; ++var) {
+            const int wpc = var == 2 ? 4 : 3;
+            const dim3 g(cus * wpc), b(256);
+            const int reps = 64;
+            auto launch = [&] {
+                if (var == 0) hipLaunchKernelGGL((k_pipe<MH, 9>), g, b, ntiles * TILE_BYTES, 0, dB, dA, dc, ntiles, reps);
+                else if (var == 1) hipLaunchKernelGGL((k_pipe1<MH, 3>), g, b, ntiles * TILE_BYTES, 0, dB, dA, dc, ntiles, reps);
+                else hipLaunchKernelGGL((k_pipe1<MH, 4>), g, b, ntiles * TILE_BYTES, 0, dB, dA, dc, ntiles, reps);
+            };
+            int occ = 0;
+            if (var == 0) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_pipe<MH, 9>, 256, ntiles * TILE_BYTES);
+            else if (var == 1) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_pipe1<MH, 3>, 256, ntiles * TILE_BYTES);
+            else hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_pipe1<MH, 4>, 256, ntiles * TILE_BYTES);
+            launch();
+            hipDeviceSynchronize();
+            float best = 1e9f;
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEventRecord(e0);
+                for (int i = 0; i < 5; ++i) launch();
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                float ms;
+                hipEventElapsedTime(&ms, e0, e1);
+                best = ms / 5 < best ? ms / 5 : best;
+            }
+            const double tests = (double)g.x * 4 * MH * 32 * ntiles * 32 * reps;
+            printf("%s, %d workgroups/CU launched (occupancy %d): %8.3f ms  %7.2f T tests/s\n",
+                   var == 0 ? "two accumulator pairs (shipped pipeline), x-epilogue" : "ONE accumulator pair, x-epilogue", wpc, occ, best,
+                   tests / best / 1e9);
+        }
     }
     return 0;
 }
