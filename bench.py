@@ -677,6 +677,9 @@ def main(argv=None):
                        "input_sets_cycled": len(sets),
                        "touched_input_bytes": int(len(sets) * compulsory),
                        "streams": nstreams, "prewarm_s": a.prewarm_seconds,
+                       "concurrent_hint": "automatic (pvnet_amd.voting.concurrent_hint): PVNET_F_CONCURRENT on calls whose stream "
+                                          "differs from the previous call's -- i.e. in the multi-stream regions, not in single_stream; "
+                                          "the flag selects a kernel variant, never a result",
                        "parallelism": f"images sharded over {world} GPU(s); steps issued round-robin on {nstreams} "
                                       f"HIP stream(s) per GPU"},
             "roofline": {"kernel": f"{SCORE_KERNEL}<{L.wg_g * L.hpl // 2}, ...>", "bound": "mfma",

@@ -60,7 +60,7 @@ enum { C_TN0 = 0, C_TN = 1, C_STATUS = 2, C_ITEM_BASE = 3, C_NCHUNKS = 4, C_OX =
 
 constexpr int SEG_WORDS = 64;          // a segment = 64 words = 4096 pixels: the unit of K1 / K2 workgroups
 #ifndef PVNET_K1_WAVES
-#define PVNET_K1_WAVES 16
+#define PVNET_K1_WAVES 8
 #endif
 #ifndef PVNET_RT
 #define PVNET_RT 512
@@ -85,8 +85,10 @@ __device__ __forceinline__ void small_stage_prio() {
 // tools/check_kernel_resources.py enforces it for every kernel of the library at build time.
 #define PVNET_SPARE_VGPRS_(r) asm volatile("" ::: "v" #r)
 #define PVNET_SPARE_VGPRS(r) PVNET_SPARE_VGPRS_(r)
-constexpr int K1_WAVES = PVNET_K1_WAVES;  // waves per K1 workgroup (one workgroup = one segment): measured 4 -> 22.5 us,
-                                        // 8 -> 20.6 us, 16 -> 19.4 us for the 78.6 MB int64 masks of a batch of 32
+constexpr int K1_WAVES = PVNET_K1_WAVES;  // waves per K1 workgroup (one workgroup = one segment).  Alone: 4 -> 28 us, 8 -> 25.6 us,
+                                          // 16 -> 24.5 us (batch 32, int64 masks); 8 since round 3: a workgroup of 16 waves needs
+                                          // 160 VGPRs per SIMD at once, one of 8 fits beside the resident scoring waves of another
+                                          // batch (PVNET_F_CONCURRENT): +3 % with six batches in flight for -0.5 % alone
 constexpr int K1_WORDS_PER_WAVE = SEG_WORDS / K1_WAVES;  // independent loads in flight per lane
 constexpr int K2_WORDS_PER_BLOCK = SEG_WORDS;
 constexpr int THIN_BITS = 10;          // thinning probability = k / 2^THIN_BITS (oracle: subsample_threshold)
@@ -1924,7 +1926,8 @@ struct Tuning {
     int score_atomic;   // PVNET_SCORE_ATOMIC      1 (default): K4 adds its counts into `counts` with integer atomics;
                         //                         0: per-chunk uint16 count rows (`partial`) summed by K5
     int score_acc;      // PVNET_SCORE_ACC         exact mode, 8 tiles per wave: accumulator pairs of the scoring loop (2: MFMAs of the
-                        //                         next step issued around this step's votes; 1: one pair, 32 VGPRs fewer)
+                        //                         next step issued around this step's votes; 1: one pair, 32 VGPRs fewer;
+                        //                         -1 (default): 1 for calls flagged PVNET_F_CONCURRENT, else 2)
     int exact_fold;     // PVNET_EXACT_FOLD        exact mode: -1 (default) = by threshold, 0 = one cell per work item and
                         //                         hypothesis, 1 = one cell per pixel tile (band_fold1())
     int dev_stages;     // PVNET_DEV_STAGES        development aid: bit mask of the stages to launch
@@ -1939,7 +1942,7 @@ void load_tuning(Tuning& t) {
     t.score_xcd = env_int("PVNET_SCORE_XCD", 1);
     t.score_atomic = env_int("PVNET_SCORE_ATOMIC", 1);
     t.score_lds_kb = env_int("PVNET_SCORE_LDS_KB", 0);
-    t.score_acc = env_int("PVNET_SCORE_ACC", 2);
+    t.score_acc = env_int("PVNET_SCORE_ACC", -1);
     t.exact_fold = env_int("PVNET_EXACT_FOLD", -1);
     t.dev_stages = env_int("PVNET_DEV_STAGES", 0x3F);
     int dev = 0, n = 0;
@@ -2065,7 +2068,7 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
                 case 1: PV_EXACT(1, 2); break;
                 case 2: PV_EXACT(2, 2); break;
                 case 4: PV_EXACT(4, 2); break;
-                case 8: if (T.score_acc == 1) PV_EXACT(8, 1); else PV_EXACT(8, 2); break;
+                case 8: if (T.score_acc == 1 || (T.score_acc < 0 && (P.flags & PVNET_F_CONCURRENT))) PV_EXACT(8, 1); else PV_EXACT(8, 2); break;
                 default: return PVNET_E_UNSUPPORTED;
             }
 #undef PV_EXACT

@@ -178,3 +178,27 @@ def test_approx_mode_is_still_available_and_close():
     diff = (ap["counts"] - lit_counts).abs()
     tn = int(ap["tn"][:2].sum())
     assert diff.sum().item() <= 2e-6 * 256 * 9 * tn + 2 and diff.max().item() <= 3
+
+
+@pytest.mark.gpu
+def test_concurrent_hint_is_result_neutral_and_follows_the_streams():
+    """PVNET_F_CONCURRENT picks the one-accumulator scoring variant: counts, winners and key-points stay bit-identical; the
+    Python front end sets it when consecutive calls alternate streams and clears it when they stay on one."""
+    m, v, _ = batch(4, 321, 480, 640, 40)
+    ref, dref = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=5, return_debug=True, concurrent=False)
+    assert dref["concurrent"] is False
+    for thresh in (0.9, 0.99, 0.999):
+        a, da = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=thresh, seed=5, return_debug=True, concurrent=False)
+        b, db = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=thresh, seed=5, return_debug=True, concurrent=True)
+        assert db["concurrent"] is True and da["concurrent"] is False
+        assert torch.equal(da["counts"], db["counts"]) and torch.equal(a, b)
+    s1, s2 = torch.cuda.Stream(dev()), torch.cuda.Stream(dev())
+    torch.cuda.synchronize()
+    seen = []
+    for st in (s1, s1, s2, s1, s1):
+        with torch.cuda.stream(st):
+            out, d = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=5, return_debug=True)
+            seen.append(d["concurrent"])
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+    assert seen[1:] == [False, True, True, False]
