@@ -693,6 +693,9 @@ def main(argv=None):
                          "timing": "avg_launch_ms = max end - min start of the kernel's workgroups on the device's "
                                    "constant-rate clock, averaged over the launches (pvnet_vote_v3_stage_repeat): the "
                                    "duration a kernel trace reports; the event figure adds the dependent-launch boundary",
+                         "variant": "two accumulator pairs (a batch alone); the multi-stream regions of `value` run the "
+                                    "one-pair variant selected by PVNET_F_CONCURRENT, ~2 % slower per launch "
+                                    "(profiles/r03_ab_small_stage_shapes.txt)",
                          "pair_tests_per_s": pairs / score_s,
                          "vs_fp32_vector_peak": alg_tflops / PEAK_F32_TFLOPS,
                          "executed_flop_per_pair": MFMA_FLOP_PER_PAIR, "executed_tflops": exec_tflops,
