@@ -11,7 +11,8 @@ rank per GPU, rendezvous on 127.0.0.1), so `python bench.py --gpus 8` and the ex
 A "step" is one pass of the whole voting path (mask + 9-key-point vector field -> 9 key-points) over one batch of 32
 synthetic images per GPU, inputs resident in HBM.  The timed mode is the library's DEFAULT: exact mode -- matrix-pipe scoring
 whose inlier counts and winners EQUAL the reference kernels' (pvnet_vote.h, PVNET_F_LITERAL / PVNET_F_APPROX).
-The timed region -- barrier + synchronise, EXACTLY K steps, barrier + synchronise, max over ranks -- is run --regions
+The timed region -- barrier + synchronise, EXACTLY K steps, synchronise [each rank's clock stops when ITS K steps and its
+last gather are done] + barrier, MAX of the ranks' times -- is run --regions
 times (default 15) and the MEDIAN region is reported as `value` / `ms_per_step` (a region of 20 steps lasts ~3 ms: one late
 stream moves a single region by several per cent); `regions` carries every region's rate, min, max and spread, and the
 GPU's clock and package power sampled while the regions ran.  Steps are independent batches, so they are issued round-robin on
@@ -527,14 +528,20 @@ def main(argv=None):
         torch.cuda.synchronize(dev)
 
     def fence():
+        """the bracket of a timed region: this rank's work (incl. its last gather) is complete -> clock reading -> every rank
+        has arrived (barrier) -> device idle.  Returns the clock reading: a closing bracket stops the rank's clock when ITS K
+        steps are done -- the whole job's time is the MAX of those over the ranks (taken by the caller) -- and not after the
+        barrier's own all-reduce (0.1-0.3 ms, 3-8 % of a 20-step region), which is not part of the K steps."""
         if dist is not None:
             flush()
         while pending:
             pending.pop(0).synchronize()
         torch.cuda.synchronize(dev)
+        t = time.perf_counter()
         if dist is not None:
             barrier()
         torch.cuda.synchronize(dev)
+        return t
 
     def timed(ns, steps=None, mode=None, **kw):
         """ONE timed region: warm-up, fence, exactly `steps` steps, fence; max over ranks"""
@@ -545,8 +552,7 @@ def main(argv=None):
         t0 = time.perf_counter()
         for i in range(steps):
             step(i, ns, mode, **kw)
-        fence()
-        dt_local = time.perf_counter() - t0
+        dt_local = fence() - t0
         dt = dt_local
         if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
