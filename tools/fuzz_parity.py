@@ -18,7 +18,8 @@ dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 START = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # first case (cases are seeded by their number)
 KNOBS = {"PVNET_SCORE_XCD": ["0", "1"], "PVNET_SCORE_ATOMIC": ["0", "1"], "PVNET_SCORE_WGS_PER_CU": ["0", "2", "8"],
-         "PVNET_COMPACT_KG": ["1", "3", "9"], "PVNET_EXACT_FOLD": ["0", "1"]}
+         "PVNET_COMPACT_KG": ["1", "3", "9"], "PVNET_EXACT_FOLD": ["0", "1"],
+         "PVNET_SCORE_ACC": ["1", "2"]}
 bad_exact = 0
 bad = 0
 worst = {}
