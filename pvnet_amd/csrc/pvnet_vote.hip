@@ -502,7 +502,7 @@ __global__ __launch_bounds__(64 * K1_WAVES) void mask_bits_kernel(VoteParams P) 
 // ------------------------------------------------------------------------------------------------------------
 template <bool LITERAL, int K2_KG, int VT>  // K2_KG key-points per block: grid.z = ceil(vn / K2_KG); VT: field element type
 __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
-    if (K2_KG == 1) PVNET_SPARE_VGPRS(39); else if (K2_KG <= 3) PVNET_SPARE_VGPRS(55); else PVNET_SPARE_VGPRS(87);
+    if (K2_KG == 1) PVNET_SPARE_VGPRS(39); else if (K2_KG <= 3) PVNET_SPARE_VGPRS(47); else PVNET_SPARE_VGPRS(87);
     small_stage_prio();
     const int bi = blockIdx.y;
     const int w0 = blockIdx.x * K2_WORDS_PER_BLOCK;
@@ -715,7 +715,7 @@ __device__ __forceinline__ void plan_image(const VoteParams& P, int bi) {
 // ------------------------------------------------------------------------------------------------------------
 template <bool LITERAL>
 __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
-    PVNET_SPARE_VGPRS(47);
+    PVNET_SPARE_VGPRS(39);
     small_stage_prio();
     // Workgroups go to the 8 XCDs round-robin by linear id; every block of image bi is placed on XCD bi % 8 so that
     // the two random 16-byte record reads per hypothesis (several per 128-byte line of the image's records) hit
