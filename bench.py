@@ -459,31 +459,34 @@ def main(argv=None):
     # S streams.  The path's one exchange -- the all-gather of every step's [32, 9, 2] key-points -- is BUCKETED: the
     # key-points of G consecutive steps (default G = S) are voted straight into the slots of a staging block and sent by
     # ONE RCCL all-gather of G x 2.3 KB per rank (fewer, larger collectives: a 2.3 KB gather is pure launch latency, and
-    # one per step costs the host more than the voting's six launches).  Two staging / target blocks alternate; a block is
-    # rewritten only after the gather that read it has completed (event on the communication stream).
+    # one per step costs the host more than the voting's six launches).  Four staging / target blocks rotate; a block is
+    # rewritten only after the gather that read it has completed (event on the communication stream, queried on the host).
     nstreams = max(1, a.streams)
     streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
     ws_bytes = voting.vote_layout(BATCH, H, W, VN, HN, 30000).total_bytes
     spaces = [torch.empty(ws_bytes, dtype=torch.uint8, device=dev) for _ in range(nstreams)]  # one workspace per stream:
     # calls on one stream are ordered, so they share it; nothing is allocated inside the timed regions
     G = max(1, a.gather_bucket if a.gather_bucket > 0 else nstreams)
+    NBLK = 4  # staging / target blocks in rotation
     if dist is not None:
         comm = torch.cuda.Stream(dev)
-        staging = [torch.empty((G, BATCH, VN, 2), dtype=torch.float32, device=dev) for _ in range(2)]
-        gathered = [torch.empty((world, G, BATCH, VN, 2), dtype=torch.float32, device=dev) for _ in range(2)]
-        voted = [[torch.cuda.Event() for _ in range(G)] for _ in range(2)]
-        sent = [None, None]  # event: the gather that last read staging[blk] is done
-    bucket = {"n": 0, "fill": 0}  # index of the bucket being filled, slots filled
+        staging = [torch.empty((G, BATCH, VN, 2), dtype=torch.float32, device=dev) for _ in range(NBLK)]
+        gathered = [torch.empty((world, G, BATCH, VN, 2), dtype=torch.float32, device=dev) for _ in range(NBLK)]
+        sent = [None] * NBLK  # event: the gather that last read staging[blk] is done
+    bucket = {"n": 0, "fill": 0, "used": set()}  # index of the bucket being filled, slots filled, streams that voted into it
     pending = []
 
     def flush():
         """send the filled slots of the current bucket (all G of them, except for a last partial bucket)"""
-        blk, k = bucket["n"] % 2, bucket["fill"]
+        blk, k = bucket["n"] % NBLK, bucket["fill"]
         if k == 0:
             return
+        # one event per STREAM that voted into the bucket, recorded now (it covers every vote the stream was given), instead
+        # of one per step: the communication stream is the only one that waits across streams
+        evs = [streams[si].record_event() for si in sorted(bucket["used"])]
         with torch.cuda.stream(comm):
-            for j in range(k):
-                comm.wait_event(voted[blk][j])
+            for ev in evs:
+                comm.wait_event(ev)
             # a last, partly filled bucket is sent whole (its unused slots carry the previous contents): no allocation and
             # no copy inside the timed region, one collective of the same size as every other
             w = dist.all_gather_into_tensor(gathered[blk], staging[blk], async_op=True)
@@ -491,9 +494,10 @@ def main(argv=None):
             sent[blk] = torch.cuda.Event()
             sent[blk].record(comm)
         pending.append(sent[blk])
-        del pending[:-4]  # (older gathers are ordered before these on the communication stream)
+        del pending[:-NBLK]  # (older gathers are ordered before these on the communication stream)
         bucket["n"] += 1
         bucket["fill"] = 0
+        bucket["used"] = set()
 
     def step(i, ns=nstreams, mode=None, **kw):
         m, v, _, _ = sets[i % len(sets)]
@@ -506,13 +510,15 @@ def main(argv=None):
             if dist is None:
                 return voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=SEED0 + i,
                                                      image_offset=rank * BATCH, workspace=spaces[i % ns], **mode)
-            blk, j = bucket["n"] % 2, bucket["fill"]
-            if sent[blk] is not None:
-                st.wait_event(sent[blk])  # the gather that last read this block has completed
+            blk, j = bucket["n"] % NBLK, bucket["fill"]
+            # the gather that last read this block (NBLK buckets ago) must be complete before a vote overwrites a slot: with
+            # four blocks in rotation it long is -- a host-side query, and a device-side wait only if it is not
+            if sent[blk] is not None and not sent[blk].query():
+                st.wait_event(sent[blk])
             out = voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=SEED0 + i,
                                                 image_offset=rank * BATCH, out=staging[blk][j], workspace=spaces[i % ns],
                                                 **mode)
-            voted[blk][j].record(st)
+        bucket["used"].add(i % ns)
         bucket["fill"] += 1
         if bucket["fill"] == G:
             flush()
