@@ -66,9 +66,12 @@ constexpr int SEG_WORDS = 64;          // a segment = 64 words = 4096 pixels: th
 #define PVNET_RT 512
 #endif
 #ifndef PVNET_SMALL_PRIO
-#define PVNET_SMALL_PRIO 0
+#define PVNET_SMALL_PRIO 3
 #endif
-// the small latency-bound stages may ask for issue priority over the co-resident scoring waves of other batches
+// the small latency-bound stages ask for issue priority over the co-resident scoring waves of other batches (s_setprio 3).
+// Round 1 measured nothing from it (nothing WAS resident beside the scoring kernel); since round 3 their workgroups share
+// SIMDs with the one-accumulator scoring kernel of concurrent callers, and their dependent chains finishing sooner is worth
+// +2.2 % with six batches in flight (profiles/r03_ab_small_stage_shapes.txt), nothing alone
 __device__ __forceinline__ void small_stage_prio() {
     if (PVNET_SMALL_PRIO) __builtin_amdgcn_s_setprio(PVNET_SMALL_PRIO);
 }
