@@ -200,3 +200,29 @@ def test_vote_epilogue_keeps_mfma_hazard_distance(tmp_path):
     ok = tmp_path / "ok.s"
     ok.write_text(bad.read_text().replace("s_nop 3", "s_nop 7\n\ts_nop 2"))
     assert chk.main([str(ok)]) == 0  # 8 + 3 = 11
+
+
+def test_concurrency_hint_follows_stream_alternation(monkeypatch):
+    """host logic of the PVNET_F_CONCURRENT hint (voting.concurrent_hint): explicit values win; with None the flag is set
+    exactly when a call's stream differs from the previous call's on that device (no GPU needed: the stream query is faked)."""
+    class FakeStream:
+        def __init__(self, h):
+            self.cuda_stream = h
+    cur = {"h": 11}
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda dev=None: FakeStream(cur["h"]))
+    monkeypatch.setattr(voting, "_last_stream", {})
+    dev0, dev1 = torch.device("cuda", 0), torch.device("cuda", 1)
+    assert voting.concurrent_hint(dev0, True) == voting.F_CONCURRENT and voting.concurrent_hint(dev0, False) == 0
+    assert voting._last_stream == {}                      # explicit values do not touch the history
+    seen = []
+    for h in (11, 11, 12, 11, 11, 11):
+        cur["h"] = h
+        seen.append(voting.concurrent_hint(dev0, None) != 0)
+    assert seen == [False, False, True, True, False, False]
+    cur["h"] = 99                                          # another device has its own history
+    assert voting.concurrent_hint(dev1, None) == 0 and voting.concurrent_hint(dev1, None) == 0
+    cur["h"] = 11
+    assert voting.concurrent_hint(dev0, None) == 0
+    assert voting.F_CONCURRENT == 256
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "pvnet_vote.h")).read()
+    assert re.search(r"#define\s+PVNET_F_CONCURRENT\s+256u", hdr)
