@@ -214,6 +214,11 @@ size_t pvnet_motion_workspace_bytes(int b, int h, int w, int vn);
 int pvnet_motion_voting(const void* mask, int mask_dtype, const int64_t mask_strides[3], const float* vertex,
                         const int64_t vertex_strides[5], int b, int h, int w, int vn, float* out_pts, void* workspace,
                         size_t workspace_bytes, void* stream);
+/* the same with a float16 / bfloat16 field read in place: flags = PVNET_F_VERTEX_F16 or PVNET_F_VERTEX_BF16 (0: float32);
+ * every element is widened where it is read, so the result equals pvnet_motion_voting on the widened field bit for bit */
+int pvnet_motion_voting_typed(const void* mask, int mask_dtype, const int64_t mask_strides[3], const void* vertex,
+                              const int64_t vertex_strides[5], int b, int h, int w, int vn, uint32_t flags,
+                              float* out_pts, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Op-level entry points with the reference extension's tensor layouts.
  * direct [tn,vn,2] f32, coords [tn,2] f32, idxs [hn,vn,2] i32 -> hypo_pts [hn,vn,2] f32 (fully written; degenerate

@@ -2431,7 +2431,16 @@ size_t pvnet_motion_workspace_bytes(int b, int h, int w, int vn) {
 int pvnet_motion_voting(const void* mask, int mask_dtype, const int64_t mask_strides[3], const float* vertex,
                         const int64_t vertex_strides[5], int b, int h, int w, int vn, float* out_pts, void* workspace,
                         size_t workspace_bytes, void* stream) {
+    return pvnet_motion_voting_typed(mask, mask_dtype, mask_strides, vertex, vertex_strides, b, h, w, vn, 0u, out_pts,
+                                     workspace, workspace_bytes, stream);
+}
+
+int pvnet_motion_voting_typed(const void* mask, int mask_dtype, const int64_t mask_strides[3], const void* vertex,
+                              const int64_t vertex_strides[5], int b, int h, int w, int vn, uint32_t flags, float* out_pts,
+                              void* workspace, size_t workspace_bytes, void* stream) {
     if (!mask || !mask_strides || !vertex || !vertex_strides || !out_pts || !workspace) return PVNET_E_BADARG;
+    if ((flags & PVNET_F_VERTEX_F16) && (flags & PVNET_F_VERTEX_BF16)) return PVNET_E_BADARG;
+    if (flags & ~(uint32_t)(PVNET_F_VERTEX_F16 | PVNET_F_VERTEX_BF16)) return PVNET_E_BADARG;
     if (mask_dtype < PVNET_MASK_U8 || mask_dtype > PVNET_MASK_F32) return PVNET_E_BADARG;
     size_t off[4];
     int words, nseg;
@@ -2445,7 +2454,8 @@ int pvnet_motion_voting(const void* mask, int mask_dtype, const int64_t mask_str
     P.num_classes = 1;
     P.mask_dtype = mask_dtype;
     P.mask_linear = (mask_strides[2] == 1 && mask_strides[1] == w) ? 1 : 0;
-    P.vertex = vertex;
+    P.vertex = static_cast<const float*>(vertex);  // (typed by vertex_type)
+    P.vertex_type = (flags & PVNET_F_VERTEX_F16) ? VT_F16 : (flags & PVNET_F_VERTEX_BF16) ? VT_BF16 : VT_F32;
     P.vs0 = vertex_strides[0]; P.vs1 = vertex_strides[1]; P.vs2 = vertex_strides[2]; P.vs3 = vertex_strides[3];
     P.vs4 = vertex_strides[4];
     P.b = b; P.h = h; P.w = w; P.vn = vn; P.npix = h * w; P.words = words; P.nseg = nseg;

@@ -90,6 +90,9 @@ def load_library() -> C.CDLL:
     lib.pvnet_motion_voting.restype = C.c_int
     lib.pvnet_motion_voting.argtypes = [C.c_void_p, C.c_int, i64p, f32p, i64p, C.c_int, C.c_int, C.c_int, C.c_int, f32p,
                                         C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.pvnet_motion_voting_typed.restype = C.c_int
+    lib.pvnet_motion_voting_typed.argtypes = [C.c_void_p, C.c_int, i64p, C.c_void_p, i64p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_uint32, f32p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.pvnet_vote_confidence.restype = C.c_int
     lib.pvnet_vote_confidence.argtypes = [f32p, C.c_float, f32p, C.c_uint32] + ws_tail
     lib.pvnet_vote_distribution.restype = C.c_int
@@ -520,20 +523,20 @@ def generate_hypothesis_counts(mask, vertex, round_hyp_num, inlier_thresh=0.999,
 def ransac_motion_voting(mask, vertex):
     """Drop-in for ransac_voting_gpu.py:960-981: per image, the mean over foreground pixels of (vertex + pixel
     coordinate); zeros for an image without foreground.  HIP: the mask kernel's bit mask, then only the foreground
-    vectors of the (strided) field are read and summed in float64 (``pvnet_motion_voting``)."""
+    vectors of the (strided) field are read and summed in float64 (``pvnet_motion_voting_typed``: float16 / bfloat16
+    fields are read in place and widened element by element -- the result equals the float32 call on ``vertex.float()``)."""
     lib = load_library()
     mask, vertex, b, h, w, vn, _, _, _ = _prepare(mask, vertex, 1, 0, None)
-    if vertex.dtype != torch.float32:
-        vertex = vertex.float()  # (this entry point takes float32 fields only)
     dev = vertex.device
     with torch.cuda.device(dev):
         nbytes = lib.pvnet_motion_workspace_bytes(b, h, w, vn)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         out = torch.empty((b, vn, 2), dtype=torch.float32, device=dev)
-        _check(lib.pvnet_motion_voting(C.c_void_p(mask.data_ptr()), _MASK_CODES[mask.dtype], _strides(mask, 3),
-                                       C.c_void_p(vertex.data_ptr()), _strides(vertex, 5), b, h, w, vn,
-                                       C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), C.c_size_t(nbytes),
-                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "pvnet_motion_voting")
+        _check(lib.pvnet_motion_voting_typed(C.c_void_p(mask.data_ptr()), _MASK_CODES[mask.dtype], _strides(mask, 3),
+                                             C.c_void_p(vertex.data_ptr()), _strides(vertex, 5), b, h, w, vn,
+                                             _FIELD_FLAGS[vertex.dtype], C.c_void_p(out.data_ptr()),
+                                             C.c_void_p(ws.data_ptr()), C.c_size_t(nbytes),
+                                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "pvnet_motion_voting")
     return out
 
 
