@@ -44,3 +44,51 @@ for t, d in ev:
     lvl, last = lvl + d, t
 print("time share by number of concurrent scoring kernels:", {k: f"{100 * v / span:.1f}%" for k, v in sorted(conc.items())})
 print(f"batches per ms in the window: {len(k4) / (span / 1e6):.2f}  -> {32 * len(k4) / (span / 1e9):,.0f} votings/s")
+
+# ---- which kernels run while NO scoring kernel is resident (= the exposed part of a step), per batch
+import re
+k4s = sorted(k4)
+gaps, cs, ce = [], None, None
+for s_, e_ in k4s:  # complement of the union of the scoring launches inside the window
+    if cs is None:
+        cs, ce = s_, e_
+    elif s_ <= ce:
+        ce = max(ce, e_)
+    else:
+        gaps.append((ce, s_))
+        cs, ce = s_, e_
+gap_total = sum(b - a for a, b in gaps)
+nb = max(1, len(k4))
+print(f"no scoring kernel running: {gap_total / 1e6:.2f} ms of the window = {gap_total / nb / 1e3:.1f} us per batch ({len(gaps)} gaps)")
+gl = sorted(b - a for a, b in gaps)
+if gl:
+    print("gap lengths (us) percentiles 10 / 50 / 90 / max:", [round(gl[min(len(gl) - 1, int(len(gl) * q))] / 1e3, 1) for q in (0.1, 0.5, 0.9)], round(gl[-1] / 1e3, 1),
+          "; gaps > 50 us:", sum(1 for g in gl if g > 50e3), "holding", round(sum(g for g in gl if g > 50e3) / 1e6, 2), "ms")
+    big = [(a, b) for a, b in gaps if b - a > 50e3]
+    if len(big) > 2:
+        d = sorted((big[i + 1][0] - big[i][0]) / 1e6 for i in range(len(big) - 1))
+        print("distance between the starts of consecutive long gaps (ms): median", round(d[len(d) // 2], 2), "min", round(d[0], 2), "max", round(d[-1], 2))
+
+
+def short(n):
+    m = re.search(r"(\w+_kernel)", n)
+    return m.group(1) if m else n[:40]
+
+
+alone, total, cnt = collections.Counter(), collections.Counter(), collections.Counter()
+gi = 0
+for n, s_, e_ in sorted((r for r in rows if "score" not in r[0]), key=lambda r: r[1]):
+    total[short(n)] += e_ - s_
+    cnt[short(n)] += 1
+    for a, b in gaps:  # (few hundred gaps: a linear scan is fine)
+        if b <= s_:
+            continue
+        if a >= e_:
+            break
+        alone[short(n)] += min(e_, b) - max(s_, a)
+print("per batch, microseconds: kernel  duration  of which while no scoring kernel runs")
+for n in sorted(total, key=lambda k: -total[k]):
+    print(f"  {n:28s} {total[n] / nb / 1e3:7.1f}  {alone[n] / nb / 1e3:7.1f}   (launches per batch {cnt[n] / nb:.2f}, mean {total[n] / cnt[n] / 1e3:.1f} us)")
+# scoring launches by duration: are launches stretched when they share the chip?
+durs = sorted(e_ - s_ for s_, e_ in k4)
+print("scoring launch duration percentiles 10 / 50 / 90 (us):", [round(durs[int(len(durs) * q)] / 1e3, 1) for q in (0.1, 0.5, 0.9)])
