@@ -427,6 +427,12 @@ __global__ void k_semantics_fp8(const float* __restrict__ a, const float* __rest
 #define AB_HALF(o) d[o + 0], cr[o + 0], d[o + 1], cr[o + 1], d[o + 2], cr[o + 2], d[o + 3], cr[o + 3], d[o + 4], cr[o + 4], \
                    d[o + 5], cr[o + 5], d[o + 6], cr[o + 6], d[o + 7], cr[o + 7]
 
+// the same eight tests with the second operand taken r registers further (semantically meaningless: does the VGPR BANK relation
+// of the two MFMA results a v_min3 reads matter?  d and cr are 16-register blocks, so d[q] and cr[q] share a bank when the blocks
+// are a multiple of four registers apart)
+#define AB_ROT(o, r) d[o + 0], cr[(o + 0 + r) & 15], d[o + 1], cr[(o + 1 + r) & 15], d[o + 2], cr[(o + 2 + r) & 15], d[o + 3], cr[(o + 3 + r) & 15], \
+                     d[o + 4], cr[(o + 4 + r) & 15], d[o + 5], cr[(o + 5 + r) & 15], d[o + 6], cr[(o + 6 + r) & 15], d[o + 7], cr[(o + 7 + r) & 15]
+
 __global__ void k_semantics(const float* __restrict__ d, const float* __restrict__ c, unsigned* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float dv[8], cv[8];
@@ -512,6 +518,8 @@ __global__ __launch_bounds__(256) void k_pipe(const u16* __restrict__ Bsrc, cons
                 else if (EPI == 6) ab_uclamp(s1[t], s2[t], AB_HALF(0));
                 else if (EPI == 7) ab_vote_only(s1[t], AB_HALF(0));
                 else if (EPI == 8) ab_min3_noabs(s1[t], f0[t], f1, f2, f3, AB_HALF(0));
+                else if (EPI == 14) ab_x(s1[t], f0[t], AB_ROT(0, 1));
+                else if (EPI == 15) ab_x(s1[t], f0[t], AB_ROT(0, 2));
                 else if (EPI == 10) ab_fp8(s1[t], s2[t], mid8, AB_HALF(0));
                 else if (EPI == 11) ab_bf8(s1[t], s2[t], mid8, AB_HALF(0));
                 else if (EPI == 12) ab_fp8_only(s1[t], AB_HALF(0));
@@ -529,6 +537,8 @@ __global__ __launch_bounds__(256) void k_pipe(const u16* __restrict__ Bsrc, cons
                 else if (EPI == 6) ab_uclamp(s1[t], s2[t], AB_HALF(8));
                 else if (EPI == 7) ab_vote_only(s1[t], AB_HALF(8));
                 else if (EPI == 8) ab_min3_noabs(s1[t], f0[t], f1, f2, f3, AB_HALF(8));
+                else if (EPI == 14) ab_x(s1[t], f0[t], AB_ROT(8, 1));
+                else if (EPI == 15) ab_x(s1[t], f0[t], AB_ROT(8, 2));
                 else if (EPI == 10) ab_fp8(s1[t], s2[t], mid8, AB_HALF(8));
                 else if (EPI == 11) ab_bf8(s1[t], s2[t], mid8, AB_HALF(8));
                 else if (EPI == 12) ab_fp8_only(s1[t], AB_HALF(8));
@@ -801,12 +811,12 @@ int main() {
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
         for (int wpc = 3; wpc <= 3; ++wpc)
-            for (int epi = 0; epi < 14; ++epi) {
+            for (int epi = 0; epi < 16; ++epi) {
                 const dim3 g(cus * wpc), b(256);
                 const int reps = 64;
                 auto launch = [&] {
 #define LAUNCH(E) case E: hipLaunchKernelGGL((k_pipe<MH, E>), g, b, ntiles * TILE_BYTES, 0, dB, dA, dc, ntiles, reps); break;
-                    switch (epi) { LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) LAUNCH(9) LAUNCH(10) LAUNCH(11) LAUNCH(12) LAUNCH(13) }
+                    switch (epi) { LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) LAUNCH(9) LAUNCH(10) LAUNCH(11) LAUNCH(12) LAUNCH(13) LAUNCH(14) LAUNCH(15) }
 #undef LAUNCH
                 };
                 launch();
@@ -832,6 +842,8 @@ int main() {
                        epi == 11 ? "a/b: y = clamp min3, cvt_pk_bf8, 2 x sad_u8 (2.0)" :
                        epi == 12 ? "a/b: y = clamp min3, cvt_pk_fp8 only       (1.5+)" :
                        epi == 13 ? "a/b: y = clamp min3, sad_u8 on raw bits    (1.5)" :
+                       epi == 14 ? "x-epilogue, second operand one register on (bank +1)" :
+                       epi == 15 ? "x-epilogue, second operand two registers on (bank +2)" :
                                   "a/b: x = min3(a, b, 1), min3 |x|, cvt_pknorm, add3 (2.25)",
                        best, tests / best / 1e9);
             }
