@@ -558,6 +558,65 @@ __global__ __launch_bounds__(256) void k_pipe(const u16* __restrict__ Bsrc, cons
             s1[t] ^ s2[t] ^ __builtin_bit_cast(unsigned, f0[t]) ^ __builtin_bit_cast(unsigned, f1 + f2 + f3);
 }
 
+// PIPE 2: two accumulator pairs as shipped, but BOTH MFMAs of the next step issued before the votes of this one (instead of one
+// before each half); PIPE 3: both issued between the two halves
+template <int MH, int ORDER>
+__global__ __launch_bounds__(256) void k_pipe2(const u16* __restrict__ Bsrc, const u16* __restrict__ Asrc,
+                                               unsigned* __restrict__ counts, int ntiles, int reps) {
+    extern __shared__ __attribute__((aligned(16))) u16 lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    for (int i = threadIdx.x; i < ntiles * TILE_BYTES / 2; i += 256) lds[i] = Asrc[i];
+    bf16x8 B[MH];
+    unsigned s1[MH];
+    float f0[MH];
+#pragma unroll
+    for (int t = 0; t < MH; ++t) {
+        const int j = (wave * MH + t) * 32 + (lane & 31);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) B[t][k] = __builtin_bit_cast(__bf16, Bsrc[j * 16 + half * 8 + k]);
+        s1[t] = 0u;
+        f0[t] = 3e38f;
+    }
+    __syncthreads();
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const char* lbase = reinterpret_cast<const char*>(lds) + (lane & 31) * 32 + half * 16;
+    for (int r = 0; r < reps; ++r) {
+        bf16x8 Acr = *reinterpret_cast<const bf16x8*>(lbase), Ad = *reinterpret_cast<const bf16x8*>(lbase + 1024);
+        f32x16 cr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Acr, B[0], zero, 0, 0, 0);
+        f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ad, B[0], zero, 0, 0, 0);
+        for (int tile = 0; tile < ntiles; ++tile) {
+            const int nt = tile + 1 < ntiles ? tile + 1 : tile;
+            const bf16x8 Ncr = *reinterpret_cast<const bf16x8*>(lbase + nt * TILE_BYTES);
+            const bf16x8 Nd = *reinterpret_cast<const bf16x8*>(lbase + nt * TILE_BYTES + 1024);
+#pragma unroll
+            for (int t = 0; t < MH; ++t) {
+                f32x16 cr2, d2;
+                if (ORDER == 2) {
+                    cr2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Acr : Ncr, B[(t + 1) % MH], zero, 0, 0, 0);
+                    d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Ad : Nd, B[(t + 1) % MH], zero, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                ab_x(s1[t], f0[t], AB_HALF(0));
+                __builtin_amdgcn_sched_barrier(0);
+                if (ORDER == 3) {
+                    cr2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Acr : Ncr, B[(t + 1) % MH], zero, 0, 0, 0);
+                    d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Ad : Nd, B[(t + 1) % MH], zero, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                ab_x(s1[t], f0[t], AB_HALF(8));
+                __builtin_amdgcn_sched_barrier(0);
+                cr = cr2;
+                d = d2;
+            }
+            Acr = Ncr;
+            Ad = Nd;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MH; ++t)
+        counts[(((size_t)blockIdx.x * 4 + wave) * MH + t) * 64 + lane] = s1[t] ^ __builtin_bit_cast(unsigned, f0[t]);
+}
+
 // PIPE 1: the same work with ONE accumulator pair -- the two MFMAs of a step are issued and their 32 results consumed by the
 // same wave right away (the wave waits for the matrix pipe; the SIMD's other waves fill the gap).  32 VGPRs fewer.
 template <int MH, int WPE>
@@ -861,19 +920,23 @@ int main() {
         hipMemcpy(dA, As.data(), As.size() * 2, hipMemcpyHostToDevice);
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
-        for (int var = 0; var < 3; ++var) {
+        for (int var = 0; var < 5; ++var) {
             const int wpc = var == 2 ? 4 : 3;
             const dim3 g(cus * wpc), b(256);
             const int reps = 64;
             auto launch = [&] {
                 if (var == 0) hipLaunchKernelGGL((k_pipe<MH, 9>), g, b, ntiles * TILE_BYTES, 0, dB, dA, dc, ntiles, reps);
                 else if (var == 1) hipLaunchKernelGGL((k_pipe1<MH, 3>), g, b, ntiles * TILE_BYTES, 0, dB, dA, dc, ntiles, reps);
-                else hipLaunchKernelGGL((k_pipe1<MH, 4>), g, b, ntiles * TILE_BYTES, 0, dB, dA, dc, ntiles, reps);
+                else if (var == 2) hipLaunchKernelGGL((k_pipe1<MH, 4>), g, b, ntiles * TILE_BYTES, 0, dB, dA, dc, ntiles, reps);
+                else if (var == 3) hipLaunchKernelGGL((k_pipe2<MH, 2>), g, b, ntiles * TILE_BYTES, 0, dB, dA, dc, ntiles, reps);
+                else hipLaunchKernelGGL((k_pipe2<MH, 3>), g, b, ntiles * TILE_BYTES, 0, dB, dA, dc, ntiles, reps);
             };
             int occ = 0;
             if (var == 0) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_pipe<MH, 9>, 256, ntiles * TILE_BYTES);
             else if (var == 1) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_pipe1<MH, 3>, 256, ntiles * TILE_BYTES);
-            else hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_pipe1<MH, 4>, 256, ntiles * TILE_BYTES);
+            else if (var == 2) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_pipe1<MH, 4>, 256, ntiles * TILE_BYTES);
+            else if (var == 3) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_pipe2<MH, 2>, 256, ntiles * TILE_BYTES);
+            else hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_pipe2<MH, 3>, 256, ntiles * TILE_BYTES);
             launch();
             hipDeviceSynchronize();
             float best = 1e9f;
@@ -888,7 +951,8 @@ int main() {
             }
             const double tests = (double)g.x * 4 * MH * 32 * ntiles * 32 * reps;
             printf("%s, %d workgroups/CU launched (occupancy %d): %8.3f ms  %7.2f T tests/s\n",
-                   var == 0 ? "two accumulator pairs (shipped pipeline), x-epilogue" : "ONE accumulator pair, x-epilogue", wpc, occ, best,
+                   var == 0 ? "two accumulator pairs (shipped pipeline), x-epilogue" : var <= 2 ? "ONE accumulator pair, x-epilogue" :
+                   var == 3 ? "two pairs, BOTH next MFMAs before this step's votes" : "two pairs, both next MFMAs between the halves", wpc, occ, best,
                    tests / best / 1e9);
         }
     }
