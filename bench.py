@@ -348,16 +348,20 @@ def parity_check(sets, rank, o64_images=BATCH, ref_images=8, max_sets=2):
     from oracle import ransac_voting_oracle as O
     cref.build()
     cores = usable_cores()
-    tot = fl_eq = lo_eq = fo_eq = cnt_eq = 0
+    tot = fl_eq = lo_eq = fo_eq = cnt_eq = conc_eq = 0
     max_px_c = max_px_lit = 0.0
     max_count_diff = 0
     ref_eq = ref_tot = 0
     for s, (m, v, mask, planar) in enumerate(sets[:max_sets]):
         fast, df = voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=SEED0 + s,
-                                                 image_offset=rank * BATCH, return_debug=True)
+                                                 image_offset=rank * BATCH, return_debug=True, concurrent=False)
         fast = fast.cpu().numpy()
         wf = df["win"].cpu().numpy().copy()
         cf = df["counts"].clone()
+        # the kernel variant the multi-stream regions ran (PVNET_F_CONCURRENT): the same integers, the same key-points
+        conc, dc = voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=SEED0 + s,
+                                                 image_offset=rank * BATCH, return_debug=True, concurrent=True)
+        conc_eq += int((cf == dc["counts"]).all(2).sum()) if bool((torch.from_numpy(fast).to(conc.device) == conc).all()) else 0
         if s == 0 and ref_images > 0 and refkernels.available("off"):
             for bi in range(min(ref_images, BATCH)):  # the reference's kernel on the path's own compacted pixels
                 tn = int(df["tn"][bi])
@@ -397,7 +401,7 @@ def parity_check(sets, rank, o64_images=BATCH, ref_images=8, max_sets=2):
         fo_eq += int((wf[:, :, 0] == wi).sum())
         max_px_c = max(max_px_c, float(np.abs(fast - ref).max()))
         max_px_lit = max(max_px_lit, float(np.abs(fast - lit).max()))
-    out = {"keypoints_checked": tot, "hypotheses_per_keypoint": HN,
+    out = {"keypoints_checked": tot, "hypotheses_per_keypoint": HN, "counts_equal_concurrent_variant": conc_eq,
            "counts_equal_literal": cnt_eq, "max_count_diff_vs_literal": max_count_diff,
            "counts_equal_reference": ref_eq if ref_tot else None, "reference_keypoints_checked": ref_tot,
            "reference": "oracle/_ref/libpvnet_refkernels.so: ransac_voting_kernel.cu:88-126 compiled for gfx950 from the "
@@ -414,7 +418,7 @@ def parity_check(sets, rank, o64_images=BATCH, ref_images=8, max_sets=2):
                                              image_offset=rank * BATCH).cpu().numpy()
         out["max_px_vs_oracle64"] = float(np.abs(fast[:k] - o64).max())
         out["oracle64_images"] = k
-    out["pass"] = bool(out["winners_equal"] and cnt_eq == tot and (ref_tot == 0 or ref_eq == ref_tot) and
+    out["pass"] = bool(out["winners_equal"] and cnt_eq == tot and conc_eq == tot and (ref_tot == 0 or ref_eq == ref_tot) and
                        max_px_c <= 1e-3 and out.get("max_px_vs_oracle64", 0.0) <= 1e-3)
     out["mode"] = "exact (the library's default: bf16x3 MFMA scoring + literal re-evaluation inside the rounding band): " \
                   "the mode the timed region ran"
