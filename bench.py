@@ -579,9 +579,6 @@ def main(argv=None):
         k = len(xs) // 2
         return xs[k] if len(xs) % 2 else 0.5 * (xs[k - 1] + xs[k])
 
-    if os.environ.get("BENCH_GC", "1") == "0":  # development: is the collector behind the holes in the stream of launches?
-        import gc
-        gc.disable()
     MAIN = {"approx": True} if a.approx else {}
     t_pre = time.perf_counter()                      # device pre-warm (untimed, reported in config.prewarm_s)
     i_pre = 0

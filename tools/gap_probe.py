@@ -23,13 +23,20 @@ ws = [torch.empty(L.total_bytes, dtype=torch.uint8, device=dev) for _ in range(S
 outs = [torch.empty((32, 9, 2), dtype=torch.float32, device=dev) for _ in range(S)]
 
 
+import time
+host = []
+
+
 def run(n, events=None):
     for i in range(n):
         m, v = sets[i % 4]
+        t0 = time.perf_counter()
         with torch.cuda.stream(streams[i % S]):
             voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=i, workspace=ws[i % S], out=outs[i % S])
             if events is not None:
                 events[i].record(streams[i % S])
+        if events is not None:
+            host.append(time.perf_counter() - t0)
 
 
 run(60)
@@ -37,8 +44,14 @@ torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
 start = torch.cuda.Event(enable_timing=True)
 start.record(streams[0])
+t_issue0 = time.perf_counter()
 run(K, ev)
+t_issue = time.perf_counter() - t_issue0
 torch.cuda.synchronize()
+t_all = time.perf_counter() - t_issue0
+h = np.array(host) * 1e6
+print(f"host: issuing {K} calls took {t_issue * 1e3:.1f} ms of the {t_all * 1e3:.1f} ms until the device was idle; per call (us): median {np.median(h):.1f}, "
+      f"p90 {np.percentile(h, 90):.1f}, p99 {np.percentile(h, 99):.1f}, max {h.max():.1f}; calls above 100 us: {(h > 100).sum()} holding {h[h > 100].sum() / 1e3:.1f} ms")
 t = np.sort(np.array([start.elapsed_time(e) for e in ev]))  # ms
 d = np.diff(t) * 1e3  # us
 steady = d[50:-20]
