@@ -1213,6 +1213,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const uint4* lbase = s_t + col * 2 + half;
 
+    // TIMED only: shader-clock cycles of this workgroup's wave 0 per phase (0 staging incl. the wait for its loads and the
+    // barrier, 1 scoring loop, 2 count flush + cell list + barrier, 3 re-evaluation + the next item's first barrier)
+    unsigned long long ph[4] = {0ull, 0ull, 0ull, 0ull}, tprev = 0ull;
+#define PV_PHASE(i)                                                     \
+    do {                                                                \
+        if (TIMED) {                                                    \
+            const unsigned long long now_ = (unsigned long long)clock64(); \
+            ph[i] += now_ - tprev;                                      \
+            tprev = now_;                                               \
+        }                                                               \
+    } while (0)
+    if (TIMED) tprev = (unsigned long long)clock64();
     const ItemRange ir = my_items(P, total);
     for (int item = ir.first; item < ir.end; item += ir.step) {
         const int4 desc = P.items[item];
@@ -1226,6 +1238,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         const int h0 = hslice + wave * MH * 32;         // this wave's first hypothesis
 
         __syncthreads();  // the previous item's tiles, raw records and cell list have been consumed
+        PV_PHASE(3);
         if (threadIdx.x == 0) s_ncell = 0;
         int tid = threadIdx.x;  // opaque copies of the thread index: what staging and re-evaluation derive from it is
         asm volatile("" : "+v"(tid));  // recomputed per item instead of staying in VGPRs across the scoring loop
@@ -1256,6 +1269,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         for (int j = 0; j < (4 * MH * 32 + 255) / 256; ++j)
             if (tid + 256 * j < 4 * MH * 32) s_hyp[tid + 256 * j] = hreg[j];
         __syncthreads();
+        PV_PHASE(0);
 
         unsigned cnt[MH];   // wrapped vote counters of the clean cells (vote8x / votes_of_norm)
         float dmn[MH];      // min |a'|, |b'| of the open cell so far
@@ -1334,6 +1348,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             Ab = Nb;
         }
         }
+        PV_PHASE(1);
         // ---- clean cells: their counts; flagged cells: into the item's list
         const unsigned all_groups = 1u;  // FOLD = 0: the one cell of the item
         int colx = col;  // opaque copy: keeps the eight per-tile addresses below from being hoisted above the scoring loop,
@@ -1370,6 +1385,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             }
         }
         __syncthreads();
+        PV_PHASE(2);
         // ---- flagged cells, decided by the reference's arithmetic: 16 lanes per cell, one pixel row each
         const int ncell = s_ncell;
         if (ncell > 0) {
@@ -1408,8 +1424,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     }
     if (TIMED) {
         __syncthreads();
-        if (threadIdx.x == 0) stamps[2 * blockIdx.x + 1] = (unsigned long long)wall_clock64();
+        PV_PHASE(3);
+        if (threadIdx.x == 0) {
+            stamps[2 * blockIdx.x + 1] = (unsigned long long)wall_clock64();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stamps[2 * gridDim.x + 4 * blockIdx.x + i] = ph[i];  // (tools/phase_probe.py)
+        }
     }
+#undef PV_PHASE
 }
 
 // profiling helper of pvnet_vote_v3_stage_repeat: acc[0] += (max end - min start) over the n workgroup slots
@@ -2342,7 +2364,7 @@ int pvnet_vote_v3_stage_repeat(const void* mask, int mask_dtype, const int64_t m
     // complete call rewrites it), when the scoring grid's slots fit there
     const long long score_wgs = tuning().wgs_per_cu > 0 ? (long long)tuning().cus * tuning().wgs_per_cu : (1ll << 40);
     const bool device_clock = stage == PVNET_STAGE_SCORE && !(P.flags & PVNET_F_LITERAL) && P.mode &&
-                              score_wgs * 16 <= (long long)sizeof(int32_t) * P.b * P.cap;
+                              score_wgs * 48 <= (long long)sizeof(int32_t) * P.b * P.cap;
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(P.ctrl + P.b * CTRL_STRIDE + 2);
     if (rc == 0 && device_clock) {
         for (int i = 0; rc == 0 && i < repeats; ++i) {
