@@ -129,23 +129,33 @@ def build_canary(force: bool = False, verbose: bool = False):
 def check_resources() -> None:
     """the spare-VGPR-granule rule is enforced AT BUILD TIME, not only by a CPU test that needs hipcc: a library
     whose kernels use their allocation to the last granule is not produced (tools/check_kernel_resources.py; the same for
-    the hand-placed MFMA epilogues, tools/check_mfma_hazard.py)."""
+    the hand-placed MFMA epilogues, tools/check_mfma_hazard.py).  The checkers compile the sources to assembly themselves;
+    they run on the freshly built library's sources BEFORE it replaces the previous one (a failing check -- or a
+    broken checker environment -- must not take a working library away).  PVNET_BUILD_UNCHECKED=1 skips them (experiments)."""
+    if os.environ.get("PVNET_BUILD_UNCHECKED") == "1":
+        print("pvnet_amd.build: PVNET_BUILD_UNCHECKED=1 -- register / MFMA-hazard checks SKIPPED (experiment build)", file=sys.stderr)
+        return
     for tool in ("check_kernel_resources.py", "check_mfma_hazard.py"):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)], capture_output=True, text=True)
         if r.returncode != 0:
-            if os.path.exists(LIB):
-                os.remove(LIB)
-            raise RuntimeError(f"pvnet_amd.build: tools/{tool} rejects this build (library removed):\n" + r.stdout[-3000:] + r.stderr[-1000:])
+            raise RuntimeError(f"pvnet_amd.build: tools/{tool} rejects this build (the previous library, if any, is kept):\n"
+                               + r.stdout[-3000:] + r.stderr[-1000:])
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     build_pnp(force, verbose)
     if force or not up_to_date():
-        cmd = [hipcc_path()] + flags() + SRC + ["-o", LIB]
+        tmp = LIB + ".new"
+        cmd = [hipcc_path()] + flags() + SRC + ["-o", tmp]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        check_resources()
+        try:
+            subprocess.check_call(cmd)
+            check_resources()
+            os.replace(tmp, LIB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     build_ext(force, verbose)
     build_canary(force, verbose)
     return LIB

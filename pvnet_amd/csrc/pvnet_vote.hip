@@ -349,7 +349,7 @@ __device__ __forceinline__ void a_rows_exact(float4 q, float tau, float ox, floa
         if (near_gate) dead = norm1_literal(nz, q.w) <= kF1e6;
     }
     if (dead) {
-        ahi.w = bhi.w = pk(0u, never);
+        ahi.w = pk(0u, never);  // dt' = -4, cr' = 0: x = -4, no vote and no flag
         return;
     }
     if (e >= 127u + 61u) return;    // finite but >= 2^61: the reference's nx * nx may overflow -- zero rows: decided literally
@@ -364,8 +364,8 @@ __device__ __forceinline__ void a_rows_exact(float4 q, float tau, float ox, floa
     const float Tx = tau * Mx, Ty = tau * My;
     const float Ec = fmaf(cx, My, -cy * Mx);                    // cr = hx My - hy Mx - Ec
     const float Ed = fmaf(cx, Tx, cy * Ty);                     // dt = hx Tx + hy Ty - Ed
-    a_row(Tx - My, Ty + Mx, Ec - Ed, alo, ahi);                 // a = dt - cr
-    a_row(Tx + My, Ty - Mx, -Ec - Ed, blo, bhi);                // b = dt + cr
+    a_row(Tx, Ty, -Ed, alo, ahi);                               // dt' rows
+    a_row(My, -Mx, -Ec, blo, bhi);                              // cr' rows
 }
 
 __device__ __forceinline__ int wave_reduce_add(int v) {
@@ -800,12 +800,18 @@ __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
 // records of an (image, key-point) are then fetched through ONE L2 instead of once per XCD.  Any placement gives the
 // same result -- the mapping is a permutation of items over workgroups.
 struct ItemRange { int first, end, step; };
+// CONTIG: a workgroup takes a contiguous run of its XCD's eighth instead of a strided sample -- consecutive items are
+// consecutive pixel groups of one (image, key-point), so the run keeps its B columns, hypotheses and vote counters (round 4)
+template <bool CONTIG = false>
 __device__ __forceinline__ ItemRange my_items(const VoteParams& P, int total) {
     if (P.score_xcd && (gridDim.x & 7u) == 0 && gridDim.x >= 8) {
-        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, n = (int)(gridDim.x >> 3);
         const int lo = (int)((long long)total * x >> 3), hi = (int)((long long)total * (x + 1) >> 3);
-        return {lo + j, hi, (int)(gridDim.x >> 3)};
+        if (CONTIG) return {lo + (int)((long long)(hi - lo) * j / n), lo + (int)((long long)(hi - lo) * (j + 1) / n), 1};
+        return {lo + j, hi, n};
     }
+    if (CONTIG)
+        return {(int)((long long)total * blockIdx.x / gridDim.x), (int)((long long)total * (blockIdx.x + 1) / gridDim.x), 1};
     return {(int)blockIdx.x, total, (int)gridDim.x};
 }
 
@@ -1085,18 +1091,18 @@ __device__ __forceinline__ void vote8x(unsigned& acc, float& dm, float a0, float
     float x0, x1, x2, x3;
     unsigned w0, w1;
     asm volatile(
-        "v_min3_f32 %2, %8, %9, 1.0\n"
-        "v_min3_f32 %3, %10, %11, 1.0\n"
-        "v_min3_f32 %4, %12, %13, 1.0\n"
-        "v_min3_f32 %5, %14, %15, 1.0\n"
+        "v_sub_f32_e64 %2, %8, |%9|\n"
+        "v_sub_f32_e64 %3, %10, |%11|\n"
+        "v_sub_f32_e64 %4, %12, |%13|\n"
+        "v_sub_f32_e64 %5, %14, |%15|\n"
         "v_min3_f32 %1, %1, |%2|, |%3|\n"
         "v_cvt_pknorm_u16_f32 %6, %2, %3\n"
-        "v_min3_f32 %2, %16, %17, 1.0\n"
-        "v_min3_f32 %3, %18, %19, 1.0\n"
+        "v_sub_f32_e64 %2, %16, |%17|\n"
+        "v_sub_f32_e64 %3, %18, |%19|\n"
         "v_min3_f32 %1, %1, |%4|, |%5|\n"
         "v_cvt_pknorm_u16_f32 %7, %4, %5\n"
-        "v_min3_f32 %4, %20, %21, 1.0\n"
-        "v_min3_f32 %5, %22, %23, 1.0\n"
+        "v_sub_f32_e64 %4, %20, |%21|\n"
+        "v_sub_f32_e64 %5, %22, |%23|\n"
         "v_add3_u32 %0, %6, %7, %0\n"
         "v_min3_f32 %1, %1, |%2|, |%3|\n"
         "v_cvt_pknorm_u16_f32 %6, %2, %3\n"
@@ -1124,18 +1130,18 @@ __device__ __forceinline__ void vote8x_open(unsigned& acc, float& dm, float a0, 
     float x0, x1, x2, x3;
     unsigned w0, w1;
     asm volatile(
-        "v_min3_f32 %2, %8, %9, 1.0\n"
-        "v_min3_f32 %3, %10, %11, 1.0\n"
-        "v_min3_f32 %4, %12, %13, 1.0\n"
-        "v_min3_f32 %5, %14, %15, 1.0\n"
+        "v_sub_f32_e64 %2, %8, |%9|\n"
+        "v_sub_f32_e64 %3, %10, |%11|\n"
+        "v_sub_f32_e64 %4, %12, |%13|\n"
+        "v_sub_f32_e64 %5, %14, |%15|\n"
         "v_min_f32_e64 %1, |%2|, |%3|\n"
         "v_cvt_pknorm_u16_f32 %6, %2, %3\n"
-        "v_min3_f32 %2, %16, %17, 1.0\n"
-        "v_min3_f32 %3, %18, %19, 1.0\n"
+        "v_sub_f32_e64 %2, %16, |%17|\n"
+        "v_sub_f32_e64 %3, %18, |%19|\n"
         "v_min3_f32 %1, %1, |%4|, |%5|\n"
         "v_cvt_pknorm_u16_f32 %7, %4, %5\n"
-        "v_min3_f32 %4, %20, %21, 1.0\n"
-        "v_min3_f32 %5, %22, %23, 1.0\n"
+        "v_sub_f32_e64 %4, %20, |%21|\n"
+        "v_sub_f32_e64 %5, %22, |%23|\n"
         "v_add_u32_e32 %0, %6, %7\n"
         "v_min3_f32 %1, %1, |%2|, |%3|\n"
         "v_cvt_pknorm_u16_f32 %6, %2, %3\n"
@@ -1152,18 +1158,18 @@ __device__ __forceinline__ void vote8x_close(unsigned& cnt, unsigned& flg, unsig
     float x0, x1, x2, x3;
     unsigned w0, w1;
     asm volatile(
-        "v_min3_f32 %4, %10, %11, 1.0\n"
-        "v_min3_f32 %5, %12, %13, 1.0\n"
-        "v_min3_f32 %6, %14, %15, 1.0\n"
-        "v_min3_f32 %7, %16, %17, 1.0\n"
+        "v_sub_f32_e64 %4, %10, |%11|\n"
+        "v_sub_f32_e64 %5, %12, |%13|\n"
+        "v_sub_f32_e64 %6, %14, |%15|\n"
+        "v_sub_f32_e64 %7, %16, |%17|\n"
         "v_min3_f32 %3, %3, |%4|, |%5|\n"
         "v_cvt_pknorm_u16_f32 %8, %4, %5\n"
-        "v_min3_f32 %4, %18, %19, 1.0\n"
-        "v_min3_f32 %5, %20, %21, 1.0\n"
+        "v_sub_f32_e64 %4, %18, |%19|\n"
+        "v_sub_f32_e64 %5, %20, |%21|\n"
         "v_min3_f32 %3, %3, |%6|, |%7|\n"
         "v_cvt_pknorm_u16_f32 %9, %6, %7\n"
-        "v_min3_f32 %6, %22, %23, 1.0\n"
-        "v_min3_f32 %7, %24, %25, 1.0\n"
+        "v_sub_f32_e64 %6, %22, |%23|\n"
+        "v_sub_f32_e64 %7, %24, |%25|\n"
         "v_add3_u32 %2, %8, %9, %2\n"
         "v_min3_f32 %3, %3, |%4|, |%5|\n"
         "v_cvt_pknorm_u16_f32 %8, %4, %5\n"
@@ -1191,8 +1197,13 @@ constexpr float BAND_CLEAN = 1.0f;     // a cell whose minimum |a'|, |b'| reache
 // NACC = 1: one pair -- a wave issues the step's two MFMAs and consumes their results right away, the SIMD's other waves
 //           fill the wait.  tools/ubench_exact.hip: 13.48 against 13.67 T tests/s at 3 waves per SIMD -- and 32 VGPRs fewer,
 //           which other streams' small stages can use while this kernel is resident (PVNET_SCORE_ACC).
-template <int MH, int FOLD, bool TIMED, int NACC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void score_exact_kernel(VoteParams P) {
+// RUNS (round 4; cells of one pixel tile only): the workgroup's items are a CONTIGUOUS run of the list -- while the (image,
+//           key-point, hypothesis slice) stays the same, the B columns stay in registers, the hypotheses in LDS and the clean cells'
+//           votes in their counters: loaded / flushed once per run instead of once per 256-pixel item.  Same-box A/B
+//           (profiles/r04_ab_runs.txt): +2 % with six batches in flight (less work), -4.5 % for a batch alone (the contiguous
+//           mapping itself: a launch of strided items ends more evenly) -- so it is what calls flagged PVNET_F_CONCURRENT run.
+template <int MH, int FOLD, bool TIMED, int NACC, bool RUNS_>
+__device__ __forceinline__ void score_exact_body(VoteParams P) {
     if (MH == 8 && NACC == 2) PVNET_SPARE_VGPRS(167);
     else if (MH == 8) PVNET_SPARE_VGPRS(135);
     else if (MH == 4) PVNET_SPARE_VGPRS(143);
@@ -1225,7 +1236,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         }                                                               \
     } while (0)
     if (TIMED) tprev = (unsigned long long)clock64();
-    const ItemRange ir = my_items(P, total);
+    constexpr bool RUNS = RUNS_ && FOLD == 1;
+    bf16x8 B[MH];
+    unsigned cnt[MH];   // wrapped vote counters of the clean cells (vote8x / votes_of_norm)
+#pragma unroll
+    for (int t = 0; t < MH; ++t) cnt[t] = 0u;
+    long long run_key = -1;      // (image, key-point) * slices + slice of the run the counters belong to
+    int run_h0 = 0, run_items = 0;
+    size_t run_bk = 0;
+    auto flush_counts = [&](size_t fbk, int fh0) {   // the clean cells' votes of a finished item / run, hypothesis tiles in pairs
+        int32_t* const pc = P.counts + fbk * P.hn_pad + fh0;
+        int lanex = threadIdx.x;
+        asm volatile("" : "+v"(lanex));   // (opaque: keeps the eight addresses from being hoisted above the scoring loop)
+        lanex &= 63;
+        if (MH >= 2) {  // lanes 0..31 finish tile t, lanes 32..63 tile t + 1
+#pragma unroll
+            for (int t = 0; t + 1 < MH; t += 2) {
+                const int c = votes_of_norm(half_wave_sum2(cnt[t], cnt[t + 1]));
+                if (c > 0) atomicAdd(pc + t * 32 + lanex, c);
+            }
+        } else {
+            const int c = votes_of_norm(half_wave_sum2(cnt[0], cnt[0]));
+            if (lanex < 32 && c > 0) atomicAdd(pc + lanex, c);
+        }
+#pragma unroll
+        for (int t = 0; t < MH; ++t) cnt[t] = 0u;
+    };
+    const ItemRange ir = my_items<RUNS>(P, total);
     for (int item = ir.first; item < ir.end; item += ir.step) {
         const int4 desc = P.items[item];
         const int bi = desc.x, k = desc.y, cg = desc.z, hq = desc.w;
@@ -1236,22 +1273,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         const int tpad = (tn + PAD - 1) / PAD * PAD;
         const int hslice = hq * 4 * MH * 32;            // first hypothesis of this work item
         const int h0 = hslice + wave * MH * 32;         // this wave's first hypothesis
+        const long long key = (long long)bk * (P.hgroups / P.wg_g) + hq;
+        // workgroup-uniform: a new run (the counters hold < 65536 votes per half: a run is cut after 256 items)
+        const bool fresh = !RUNS || key != run_key || run_items >= 256;
 
         __syncthreads();  // the previous item's tiles, raw records and cell list have been consumed
         PV_PHASE(3);
         if (threadIdx.x == 0) s_ncell = 0;
         int tid = threadIdx.x;  // opaque copies of the thread index: what staging and re-evaluation derive from it is
         asm volatile("" : "+v"(tid));  // recomputed per item instead of staying in VGPRs across the scoring loop
-        float2 hreg[(4 * MH * 32 + 255) / 256];  // the item's hypotheses: loaded now, parked in LDS after the staging arithmetic
+        float2 hreg[(4 * MH * 32 + 255) / 256];  // the run's hypotheses: loaded now, parked in LDS after the staging arithmetic
+        if (fresh) {
+            if (RUNS && run_key >= 0) flush_counts(run_bk, run_h0);
+            run_key = key;
+            run_bk = bk;
+            run_h0 = h0;
+            run_items = 0;
 #pragma unroll
-        for (int j = 0; j < (4 * MH * 32 + 255) / 256; ++j)
-            hreg[j] = (tid + 256 * j < 4 * MH * 32) ? P.hyp[bk * P.hn_pad + hslice + tid + 256 * j] : make_float2(0.f, 0.f);
-        bf16x8 B[MH];
+            for (int j = 0; j < (4 * MH * 32 + 255) / 256; ++j)
+                hreg[j] = (tid + 256 * j < 4 * MH * 32) ? P.hyp[bk * P.hn_pad + hslice + tid + 256 * j] : make_float2(0.f, 0.f);
 #pragma unroll
-        for (int t = 0; t < MH; ++t) {
-            const uint4 raw = P.hypb[(bk * P.hn_pad + h0 + t * 32 + col) * 2 + half];
-            B[t] = __builtin_bit_cast(bf16x8, raw);
+            for (int t = 0; t < MH; ++t) {
+                const uint4 raw = P.hypb[(bk * P.hn_pad + h0 + t * 32 + (tid & 31)) * 2 + ((tid >> 5) & 1)];  // (column, half-wave)
+                B[t] = __builtin_bit_cast(bf16x8, raw);
+            }
         }
+        ++run_items;
         for (int i = tid; i < npx; i += 256) {
             const int p = cg * npx + i;
             float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1265,18 +1312,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             t[64] = r2;
             t[65] = r3;
         }
+        if (fresh) {
 #pragma unroll
-        for (int j = 0; j < (4 * MH * 32 + 255) / 256; ++j)
-            if (tid + 256 * j < 4 * MH * 32) s_hyp[tid + 256 * j] = hreg[j];
+            for (int j = 0; j < (4 * MH * 32 + 255) / 256; ++j)
+                if (tid + 256 * j < 4 * MH * 32) s_hyp[tid + 256 * j] = hreg[j];
+        }
         __syncthreads();
         PV_PHASE(0);
 
-        unsigned cnt[MH];   // wrapped vote counters of the clean cells (vote8x / votes_of_norm)
-        float dmn[MH];      // min |a'|, |b'| of the open cell so far
+        float dmn[MH];      // min |x| of the open cell so far
         unsigned flg[MH];   // FOLD: bit (nti - 1 - tile) set = pixel tile `tile` holds a test inside the band
 #pragma unroll
         for (int t = 0; t < MH; ++t) {
-            cnt[t] = flg[t] = 0u;
+            flg[t] = 0u;
             dmn[t] = 3.0e38f;
         }
         const int left = (tpad - cg * npx + 31) >> 5;
@@ -1353,24 +1401,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         const unsigned all_groups = 1u;  // FOLD = 0: the one cell of the item
         int colx = col;  // opaque copy: keeps the eight per-tile addresses below from being hoisted above the scoring loop,
         asm volatile("" : "+v"(colx));  // where they would cost 20 VGPRs at the point of highest pressure
-        int32_t* const pcnt = P.counts + bk * P.hn_pad + h0;
         const bool padded = h0 + MH * 32 > P.hn;  // wave-uniform: only the last slice can hold padding columns
         if (!FOLD) {
 #pragma unroll
             for (int t = 0; t < MH; ++t) cnt[t] = dmn[t] >= BAND_CLEAN ? cnt[t] : 0u;  // a flagged cell's votes are discarded
         }
-        if (MH >= 2) {  // the clean cells' votes, tiles in pairs: lanes 0..31 finish tile t, lanes 32..63 tile t + 1
-            int lanex = lane;
-            asm volatile("" : "+v"(lanex));
-#pragma unroll
-            for (int t = 0; t + 1 < MH; t += 2) {
-                const int c = votes_of_norm(half_wave_sum2(cnt[t], cnt[t + 1]));
-                if (c > 0) atomicAdd(pcnt + t * 32 + lanex, c);
-            }
-        } else {
-            const int c = votes_of_norm(half_wave_sum2(cnt[0], cnt[0]));
-            if (half == 0 && c > 0) atomicAdd(pcnt + colx, c);
-        }
+        if (!RUNS) flush_counts(bk, h0);  // (RUNS: when the run ends)
 #pragma unroll
         for (int t = 0; t < MH; ++t) {
             unsigned mask = FOLD ? flg[t] : (dmn[t] >= BAND_CLEAN ? 0u : all_groups);
@@ -1422,6 +1458,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             }
         }
     }
+    if (RUNS && run_key >= 0) flush_counts(run_bk, run_h0);
     if (TIMED) {
         __syncthreads();
         PV_PHASE(3);
@@ -1433,6 +1470,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     }
 #undef PV_PHASE
 }
+// The register allocator fills whatever budget the occupancy target leaves (3 waves per SIMD: 168 VGPRs), the library needs
+// the top granule of every allocation unused (PVNET_SPARE_VGPRS): amdgpu_num_vgpr -- a literal, hence one definition per
+// instantiation -- caps what the code may use one granule below what PVNET_SPARE_VGPRS makes the kernel allocate (the
+// backend doubles the attribute's value on targets with a unified VGPR / AGPR file, hence the / 2).
+template <int MH, int FOLD, bool TIMED, int NACC, bool RUNS> struct ScoreExact;
+#define PV_DEF_SCORE_EXACT(MH_, FOLD_, TIMED_, NACC_, RUNS_, NVGPR_)                                                     \
+    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8), amdgpu_num_vgpr(NVGPR_ / 2))) void       \
+        score_exact_kernel_##MH_##_##FOLD_##_##TIMED_##_##NACC_##_##RUNS_(VoteParams P) {                                \
+        score_exact_body<MH_, FOLD_, TIMED_ != 0, NACC_, RUNS_ != 0>(P);                                                 \
+    }                                                                                                                    \
+    template <> struct ScoreExact<MH_, FOLD_, TIMED_ != 0, NACC_, RUNS_ != 0> {                                          \
+        static constexpr void (*kernel)(VoteParams) = score_exact_kernel_##MH_##_##FOLD_##_##TIMED_##_##NACC_##_##RUNS_; \
+    };
+#define PV_DEF_SCORE_EXACT4(MH_, NACC_, RUNS_, NVGPR_)                                                                   \
+    PV_DEF_SCORE_EXACT(MH_, 0, 0, NACC_, RUNS_, NVGPR_) PV_DEF_SCORE_EXACT(MH_, 0, 1, NACC_, RUNS_, NVGPR_)              \
+    PV_DEF_SCORE_EXACT(MH_, 1, 0, NACC_, RUNS_, NVGPR_) PV_DEF_SCORE_EXACT(MH_, 1, 1, NACC_, RUNS_, NVGPR_)
+PV_DEF_SCORE_EXACT4(1, 2, 0, 104) PV_DEF_SCORE_EXACT4(2, 2, 0, 104) PV_DEF_SCORE_EXACT4(4, 2, 0, 136)
+PV_DEF_SCORE_EXACT4(8, 1, 0, 128) PV_DEF_SCORE_EXACT4(8, 2, 0, 160)
+PV_DEF_SCORE_EXACT4(8, 1, 1, 128) PV_DEF_SCORE_EXACT4(8, 2, 1, 160)
+#undef PV_DEF_SCORE_EXACT4
+#undef PV_DEF_SCORE_EXACT
 
 // profiling helper of pvnet_vote_v3_stage_repeat: acc[0] += (max end - min start) over the n workgroup slots
 __global__ __launch_bounds__(256) void ts_collect_kernel(const unsigned long long* __restrict__ stamps, int n,
@@ -1953,6 +2011,9 @@ struct Tuning {
     int score_acc;      // PVNET_SCORE_ACC         exact mode, 8 tiles per wave: accumulator pairs of the scoring loop (2: MFMAs of the
                         //                         next step issued around this step's votes; 1: one pair, 32 VGPRs fewer;
                         //                         -1 (default): 1 for calls flagged PVNET_F_CONCURRENT, else 2)
+    int score_runs;     // PVNET_SCORE_RUNS        exact mode, 8 tiles per wave: 1 = contiguous item runs per workgroup (B columns, hypotheses and
+                        //                         vote counters kept while the (image, key-point) stays), 0 = strided items;
+                        //                         -1 (default): runs for calls flagged PVNET_F_CONCURRENT
     int exact_fold;     // PVNET_EXACT_FOLD        exact mode: -1 (default) = by threshold, 0 = one cell per work item and
                         //                         hypothesis, 1 = one cell per pixel tile (band_fold1())
     int dev_stages;     // PVNET_DEV_STAGES        development aid: bit mask of the stages to launch
@@ -1969,6 +2030,7 @@ void load_tuning(Tuning& t) {
     t.score_lds_kb = env_int("PVNET_SCORE_LDS_KB", 0);
     t.score_acc = env_int("PVNET_SCORE_ACC", -1);
     t.exact_fold = env_int("PVNET_EXACT_FOLD", -1);
+    t.score_runs = env_int("PVNET_SCORE_RUNS", -1);
     t.dev_stages = env_int("PVNET_DEV_STAGES", 0x3F);
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -2079,23 +2141,33 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
             if (T.score_lds_kb > 0 && T.score_lds_kb <= 64 && lds < (size_t)T.score_lds_kb * 1024) lds = (size_t)T.score_lds_kb * 1024;
             const dim3 g((unsigned)wgs), t(256);
             const int fold = P.fold1;
-#define PV_EXACT(MH_, NACC_)                                                                                        \
+            // calls flagged PVNET_F_CONCURRENT (other batches in flight): contiguous runs + one accumulator pair; a batch alone:
+            // strided items + two pairs (PVNET_SCORE_ACC / PVNET_SCORE_RUNS force either; runs need cells of one pixel tile)
+            const bool conc = (P.flags & PVNET_F_CONCURRENT) != 0;
+            const bool one_acc = T.score_acc == 1 || (T.score_acc < 0 && conc);
+            const bool runs = fold == 1 && (T.score_runs == 1 || (T.score_runs < 0 && conc));
+#define PV_EXACT3(MH_, NACC_, RUNS_)                                                                                \
     do {                                                                                                            \
         if (timed_score) {                                                                                          \
-            if (fold == 1) hipLaunchKernelGGL((score_exact_kernel<MH_, 1, true, NACC_>), g, t, lds, s, P);          \
-            else hipLaunchKernelGGL((score_exact_kernel<MH_, 0, true, NACC_>), g, t, lds, s, P);                    \
+            if (fold == 1) hipLaunchKernelGGL((ScoreExact<MH_, 1, true, NACC_, RUNS_>::kernel), g, t, lds, s, P);   \
+            else hipLaunchKernelGGL((ScoreExact<MH_, 0, true, NACC_, RUNS_>::kernel), g, t, lds, s, P);             \
         } else {                                                                                                    \
-            if (fold == 1) hipLaunchKernelGGL((score_exact_kernel<MH_, 1, false, NACC_>), g, t, lds, s, P);         \
-            else hipLaunchKernelGGL((score_exact_kernel<MH_, 0, false, NACC_>), g, t, lds, s, P);                   \
+            if (fold == 1) hipLaunchKernelGGL((ScoreExact<MH_, 1, false, NACC_, RUNS_>::kernel), g, t, lds, s, P);  \
+            else hipLaunchKernelGGL((ScoreExact<MH_, 0, false, NACC_, RUNS_>::kernel), g, t, lds, s, P);            \
         }                                                                                                           \
     } while (0)
+#define PV_EXACT(MH_, NACC_) PV_EXACT3(MH_, NACC_, false)
             switch (mh) {
                 case 1: PV_EXACT(1, 2); break;
                 case 2: PV_EXACT(2, 2); break;
                 case 4: PV_EXACT(4, 2); break;
-                case 8: if (T.score_acc == 1 || (T.score_acc < 0 && (P.flags & PVNET_F_CONCURRENT))) PV_EXACT(8, 1); else PV_EXACT(8, 2); break;
+                case 8:
+                    if (runs) { if (one_acc) PV_EXACT3(8, 1, true); else PV_EXACT3(8, 2, true); }
+                    else { if (one_acc) PV_EXACT(8, 1); else PV_EXACT(8, 2); }
+                    break;
                 default: return PVNET_E_UNSUPPORTED;
             }
+#undef PV_EXACT3
 #undef PV_EXACT
         } else if (!literal && P.mode) {
             const int mh = P.wg_g * P.hpl / 2;  // hypotheses per item = wg_g * 64 * hpl = 4 waves * mh * 32

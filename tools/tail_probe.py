@@ -44,3 +44,13 @@ print(f"sum of workgroup lifetimes {busy:.0f} us = {busy / resident:.1f} us per 
       f"{total:.1f} us: {100 * (1 - busy / resident / total):.1f} % of the slot-time is tail / ramp")
 life = end - start
 print("workgroup lifetime (us) percentiles 5 / 50 / 95:", np.percentile(life, [5, 50, 95]).round(1))
+# the workgroups that end last: index, XCD (index % 8), position in its XCD's dispatch order, start, end
+order = np.argsort(-end)[:12]
+print("last to end:  " + "  ".join(f"wg{i}(x{i % 8},j{i // 8}) {start[i]:.0f}->{end[i]:.0f}" for i in order))
+first = np.argsort(end)[:6]
+print("first to end: " + "  ".join(f"wg{i}(x{i % 8},j{i // 8}) {start[i]:.0f}->{end[i]:.0f}" for i in first))
+# per dispatch position (j = index // 8, averaged over the 8 XCDs): start and lifetime
+jj = np.arange(grid) // 8
+for lo_j in range(0, grid // 8, 32):
+    sel = (jj >= lo_j) & (jj < lo_j + 32)
+    print(f"  j {lo_j:3d}..{lo_j + 31:3d}: start {start[sel].mean():6.1f}  lifetime {life[sel].mean():6.1f}  end {end[sel].mean():6.1f} (max {end[sel].max():6.1f})")

@@ -208,6 +208,91 @@ def body_epilogue_sad(mfma, valu):
     return lines
 
 
+# candidate (round 4): the MFMAs return dt'' = (s sigma dt + 1) / 2 and cr'' = s sigma cr / 2, so that
+#   x = clamp(dt'' - |cr''|)   [v_sub_f32 clamp, FAST class]  is exactly 1.0 (vote) / 0.0 (no vote) outside the band, in (0, 1) inside
+#   S += x  [v_add_f32]   Q += x * x  [v_fma_f32]      the cell is clean iff S == Q (x - x^2 > 0 for every x inside (0, 1)), votes = S
+# 3 fast-class operations per test + the 4-operation close.  Two chains each for S and Q.
+def body_epilogue_float(mfma, valu, chains=2):
+    lines = []
+    for q in (0, 1):
+        pd, pc = 10 + 32 * q, 26 + 32 * q
+        d = lambda i: f"v{pd + i}"
+        c = lambda i: f"v{pc + i}"
+        X = ["v78", "v79", "v80", "v81"]
+        SA, SB, QA, QB = "v76", "v82", "v77", "v83"
+        for hlf in (0, 1):
+            if mfma: lines.append(mfma_pair(1 - q, hlf))
+            if not valu: continue
+            o = 8 * hlf
+            for g in (0, 1):          # groups of four tests
+                i0 = o + 4 * g
+                lines += [f"v_sub_f32_e64 {X[j]}, {d(i0 + j)}, |{c(i0 + j)}| clamp" for j in range(4)]
+                first = hlf == 0 and g == 0
+                if first:
+                    lines += [f"v_add_f32_e32 {SA}, {X[0]}, {X[1]}", f"v_mul_f32_e32 {QA}, {X[0]}, {X[0]}",
+                              f"v_add_f32_e32 {SB}, {X[2]}, {X[3]}", f"v_mul_f32_e32 {QB}, {X[1]}, {X[1]}",
+                              f"v_fma_f32 {QA}, {X[2]}, {X[2]}, {QA}", f"v_fma_f32 {QB}, {X[3]}, {X[3]}, {QB}"]
+                else:
+                    lines += [f"v_add_f32_e32 {SA}, {SA}, {X[0]}", f"v_fma_f32 {QA}, {X[0]}, {X[0]}, {QA}",
+                              f"v_add_f32_e32 {SB}, {SB}, {X[1]}", f"v_fma_f32 {QB}, {X[1]}, {X[1]}, {QB}",
+                              f"v_add_f32_e32 {SA}, {SA}, {X[2]}", f"v_fma_f32 {QA}, {X[2]}, {X[2]}, {QA}",
+                              f"v_add_f32_e32 {SB}, {SB}, {X[3]}", f"v_fma_f32 {QB}, {X[3]}, {X[3]}, {QB}"]
+            if hlf == 1:
+                lines += [f"v_add_f32_e32 {SA}, {SA}, {SB}", f"v_add_f32_e32 {QA}, {QA}, {QB}",
+                          f"v_cmp_neq_f32_e32 vcc, {SA}, {QA}",
+                          "s_nop 0",
+                          f"v_cndmask_b32_e64 {SA}, {SA}, 0, vcc",
+                          "v_addc_co_u32_e32 v75, vcc, v75, v75, vcc",
+                          f"v_add_f32_e32 v74, v74, {SA}"]
+    return lines
+
+
+# the same with the band from packed bf16 halves: x (fast), w = cvt_pk_bf16(x, x') , votes += w (pk_add_u16), u = w - 1 (pk_sub_u16),
+# mn = min(mn, u) (pk_min_u16): 1 fast + 2 medium-class operations per test
+def body_epilogue_pk16(mfma, valu):
+    lines = []
+    for q in (0, 1):
+        pd, pc = 10 + 32 * q, 26 + 32 * q
+        d = lambda i: f"v{pd + i}"
+        c = lambda i: f"v{pc + i}"
+        X = ["v78", "v79", "v80", "v81"]
+        for hlf in (0, 1):
+            if mfma: lines.append(mfma_pair(1 - q, hlf))
+            if not valu: continue
+            o = 8 * hlf
+            for g in (0, 1):
+                i0 = o + 4 * g
+                lines += [f"v_sub_f32_e64 {X[j]}, {d(i0 + j)}, |{c(i0 + j)}| clamp" for j in range(4)]
+                lines += ["v_cvt_pk_bf16_f32 v82, v78, v79", "v_cvt_pk_bf16_f32 v83, v80, v81",
+                          "v_pk_add_u16 v76, v76, v82", "v_pk_sub_u16 v85, v82, v84",
+                          "v_pk_add_u16 v76, v76, v83", "v_pk_sub_u16 v86, v83, v84",
+                          "v_pk_min_u16 v77, v77, v85", "v_pk_min_u16 v77, v77, v86"]
+            if hlf == 1:
+                lines += ["v_cmp_gt_u32_e32 vcc, v84, v77", "s_nop 0", "v_cndmask_b32_e64 v76, v76, 0, vcc",
+                          "v_addc_co_u32_e32 v75, vcc, v75, v75, vcc", "v_add_u32_e32 v74, v74, v76"]
+    return lines
+
+
+# approximate mode's epilogue for scale: x = clamp(dt - |cr|) (fast), acc = add3(acc, x, x') (slow): 1.5 operations per test
+def body_epilogue_approx(mfma, valu):
+    lines = []
+    for q in (0, 1):
+        pd, pc = 10 + 32 * q, 26 + 32 * q
+        d = lambda i: f"v{pd + i}"
+        c = lambda i: f"v{pc + i}"
+        X = ["v78", "v79", "v80", "v81"]
+        for hlf in (0, 1):
+            if mfma: lines.append(mfma_pair(1 - q, hlf))
+            if not valu: continue
+            o = 8 * hlf
+            for g in (0, 1):
+                i0 = o + 4 * g
+                lines += [f"v_sub_f32_e64 {X[j]}, {d(i0 + j)}, |{c(i0 + j)}| clamp" for j in range(4)]
+                lines += ["v_add3_u32 v74, v78, v79, v74", "v_add3_u32 v74, v80, v81, v74"]
+    return lines
+
+
+# the same with two fast adds instead of one add3
 KERNEL = r"""
 __global__ __launch_bounds__(256) void {name}(unsigned long long* __restrict__ out, int iters) {{
     extern __shared__ char smem[];
@@ -258,13 +343,16 @@ int main(int argc, char** argv) {
     const char* filter = argc > 1 ? argv[1] : "";
     int cus = 256;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
     unsigned long long* dout;
     hipMalloc(&dout, (size_t)cus * 8 * 4 * 2 * 8);
     std::vector<unsigned long long> h((size_t)cus * 8 * 4 * 2);
     printf("# cycles per iteration per SIMD (shader clock, s_memtime), per VALU op where the case has ops; MHz = s_memtime / s_memrealtime(100 MHz)\n");
     printf("# %%-28s %%5s %%5s | waves/SIMD:", "case", "ops", "mfma");
     const int Ws[] = {1, 2, 3, 4, 5, 6, 8};
-    for (int W : Ws) printf(" %%9d", W);
+    for (int W : Ws) printf(" %%13d", W);
     printf("\n");
     for (const Case& c : cases) {
         if (filter[0] && !strstr(c.name, filter)) continue;
@@ -272,20 +360,29 @@ int main(int argc, char** argv) {
         double mhz = 0;
         for (int W : Ws) {
             const int maxw = 512 / ((c.nv + 7) / 8 * 8);
-            if (W > maxw) { printf(" %%9s", "-"); continue; }
-            const size_t lds = (size_t)(160 * 1024 / W) / 1024 * 1024 - (W == 1 ? 0 : 0);
+            if (W > maxw) { printf(" %%13s", "-"); continue; }
+            // W workgroups per CU and no more: each takes 1 / W of 156 KB of the CU's 160 KB of LDS (W + 1 would need > 160 KB for W <= 8)
+            const size_t lds = (size_t)(156 * 1024 / W) / 256 * 256;
             hipFuncSetAttribute((const void*)c.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            int occ = 0;
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)c.fn, 256, lds);
+            if (occ != W) { printf(" occ%%d!=%%d", occ, W); continue; }
             const int iters = 40000 / W;
             hipLaunchKernelGGL(c.fn, dim3(cus * W), dim3(256), lds, 0, dout, iters / 8);  // warm-up
+            hipEventRecord(e0, 0);
             hipLaunchKernelGGL(c.fn, dim3(cus * W), dim3(256), lds, 0, dout, iters);
+            hipEventRecord(e1, 0);
             if (hipDeviceSynchronize() != hipSuccess) { printf(" launch failed\n"); return 1; }
+            float wall_ms = 0.f;
+            hipEventElapsedTime(&wall_ms, e0, e1);
             hipMemcpy(h.data(), dout, (size_t)cus * W * 4 * 2 * 8, hipMemcpyDeviceToHost);
             double cyc = 0, rt = 0;
             const size_t n = (size_t)cus * W * 4;
             for (size_t i = 0; i < n; ++i) { cyc += (double)h[2 * i]; rt += (double)h[2 * i + 1]; }
             cyc /= n; rt /= n;
             mhz = cyc / rt * 100.0;
-            printf(" %%9.1f", cyc / ((double)W * iters));
+            // per-wave cycles, and (in brackets) the launch's wall time in the same unit: equal when all W workgroups per CU are resident together
+            printf(" %%6.1f[%%5.1f]", cyc / ((double)W * iters), wall_ms * 1e-3 * mhz * 1e6 / ((double)W * iters));
         }
         printf("   (%%.0f MHz)\n", mhz);
         fflush(stdout);
@@ -321,7 +418,17 @@ def main():
             kn = f"k_{name}_{'m' if wm else 'v'}"
             src.append(kernel(kn, body_ops(tmpl, wm), 64))
             cases.append(f'    {{"{name}{" +2mfma" if wm else ""}", {kn}, {NOPS}, {2 * wm}, 64}},')
-    for tag, fn in (("epi_shipped", body_epilogue), ("epi_sad16", body_epilogue_sad)):
+    def approx_adds(mf, va):
+        out = []
+        for l in body_epilogue_approx(mf, va):
+            if l.startswith("v_add3_u32"):
+                _, dst, a, b, _ = l.replace(",", "").split()
+                out += [f"v_add_u32_e32 v74, v74, {a}", f"v_add_u32_e32 v76, v76, {b}"]
+            else:
+                out.append(l)
+        return out
+    for tag, fn in (("epi_shipped", body_epilogue), ("epi_sad16", body_epilogue_sad), ("epi_float", body_epilogue_float),
+                    ("epi_pk16", body_epilogue_pk16), ("epi_approx", body_epilogue_approx), ("epi_approx_add2", approx_adds)):
         for mf, va in ((0, 1), (1, 0), (1, 1)):
             kn = f"k_{tag}_{mf}{va}"
             lines = fn(mf, va)
