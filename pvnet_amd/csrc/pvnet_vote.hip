@@ -1120,70 +1120,72 @@ __device__ __forceinline__ int votes_of_norm(unsigned acc) {
     const unsigned hi = (lo - ((acc + lo) >> 16)) & 0xFFFFu;
     return (int)(lo + hi);
 }
-// FOLD = 1 (one cell per step): the first eight tests OPEN the cell -- acc and dm are produced, not updated, which saves their
-// two initialisations -- and the second eight CLOSE it: the cell's votes join cnt only if no |x| fell below 1, and the
-// verdict is shifted into flg (v_addc_co_u32 flg = 2 flg + bad: after the item's tiles bit (nti - 1 - tile) belongs to
-// `tile`).  22 operations for the closing half: 40 per step against 36 + 7 for the same in C.
-__device__ __forceinline__ void vote8x_open(unsigned& acc, float& dm, float a0, float b0, float a1, float b1, float a2,
-                                            float b2, float a3, float b3, float a4, float b4, float a5, float b5, float a6,
-                                            float b6, float a7, float b7) {
-    float x0, x1, x2, x3;
-    unsigned w0, w1;
+// FOLD = 1 (one cell per step), round 4: the step's 40 operations in the order the two issue ports like (tools/ubench_issue.py
+// "epi_sub order 2", profiles/r04_ubench_issue.txt: 152 cycles per step against 168 for the order "MFMA, subtractions, the
+// rest" and 187 for round 3's min3 form).  A SIMD issues the fast class (v_sub_f32 here) through either of two ports, the slow
+// class (min3, pknorm, add3, cmp, cndmask) through one, and an MFMA keeps the other busy for 32 cycles -- so behind every MFMA
+// come the ten slow operations of the PREVIOUS eight tests (their x wait in eight registers), and only then the eight
+// subtractions of the next eight tests:
+//     MFMA dt(next) | slow + close (tests 8..15 of the previous step) | x = d - |c| (tests 0..7 of this step)
+//     MFMA cr(next) | slow, open   (tests 0..7 of this step)         | x = d - |c| (tests 8..15 of this step)
+// vote_subs: eight differences.  vote_slow_open: the first eight tests OPEN the cell -- acc and dm are produced, not updated.
+// vote_slow_close: the second eight CLOSE it: the cell's votes join cnt only if no |x| fell below 1, and the verdict is
+// shifted into flg (v_addc_co_u32 flg = 2 flg + bad: after the item's tiles bit (nti - 1 - tile) belongs to `tile`).
+__device__ __forceinline__ void vote_subs(float& x0, float& x1, float& x2, float& x3, float& x4, float& x5, float& x6,
+                                          float& x7, float d0, float c0, float d1, float c1, float d2, float c2, float d3,
+                                          float c3, float d4, float c4, float d5, float c5, float d6, float c6, float d7,
+                                          float c7) {
     asm volatile(
-        "v_sub_f32_e64 %2, %8, |%9|\n"
-        "v_sub_f32_e64 %3, %10, |%11|\n"
-        "v_sub_f32_e64 %4, %12, |%13|\n"
-        "v_sub_f32_e64 %5, %14, |%15|\n"
-        "v_min_f32_e64 %1, |%2|, |%3|\n"
-        "v_cvt_pknorm_u16_f32 %6, %2, %3\n"
-        "v_sub_f32_e64 %2, %16, |%17|\n"
-        "v_sub_f32_e64 %3, %18, |%19|\n"
-        "v_min3_f32 %1, %1, |%4|, |%5|\n"
-        "v_cvt_pknorm_u16_f32 %7, %4, %5\n"
-        "v_sub_f32_e64 %4, %20, |%21|\n"
-        "v_sub_f32_e64 %5, %22, |%23|\n"
-        "v_add_u32_e32 %0, %6, %7\n"
-        "v_min3_f32 %1, %1, |%2|, |%3|\n"
-        "v_cvt_pknorm_u16_f32 %6, %2, %3\n"
-        "v_min3_f32 %1, %1, |%4|, |%5|\n"
-        "v_cvt_pknorm_u16_f32 %7, %4, %5\n"
-        "v_add3_u32 %0, %6, %7, %0\n"
-        : "=&v"(acc), "=&v"(dm), "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(w0), "=&v"(w1)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5),
-          "v"(a6), "v"(b6), "v"(a7), "v"(b7));
+        "v_sub_f32_e64 %0, %8, |%9|\n"
+        "v_sub_f32_e64 %1, %10, |%11|\n"
+        "v_sub_f32_e64 %2, %12, |%13|\n"
+        "v_sub_f32_e64 %3, %14, |%15|\n"
+        "v_sub_f32_e64 %4, %16, |%17|\n"
+        "v_sub_f32_e64 %5, %18, |%19|\n"
+        "v_sub_f32_e64 %6, %20, |%21|\n"
+        "v_sub_f32_e64 %7, %22, |%23|\n"
+        : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7)
+        : "v"(d0), "v"(c0), "v"(d1), "v"(c1), "v"(d2), "v"(c2), "v"(d3), "v"(c3), "v"(d4), "v"(c4), "v"(d5), "v"(c5),
+          "v"(d6), "v"(c6), "v"(d7), "v"(c7));
 }
-__device__ __forceinline__ void vote8x_close(unsigned& cnt, unsigned& flg, unsigned acc, float dm, float a0, float b0,
-                                             float a1, float b1, float a2, float b2, float a3, float b3, float a4, float b4,
-                                             float a5, float b5, float a6, float b6, float a7, float b7) {
-    float x0, x1, x2, x3;
+__device__ __forceinline__ void vote_slow_open(unsigned& acc, float& dm, float x0, float x1, float x2, float x3, float x4,
+                                               float x5, float x6, float x7) {
     unsigned w0, w1;
     asm volatile(
-        "v_sub_f32_e64 %4, %10, |%11|\n"
-        "v_sub_f32_e64 %5, %12, |%13|\n"
-        "v_sub_f32_e64 %6, %14, |%15|\n"
-        "v_sub_f32_e64 %7, %16, |%17|\n"
-        "v_min3_f32 %3, %3, |%4|, |%5|\n"
-        "v_cvt_pknorm_u16_f32 %8, %4, %5\n"
-        "v_sub_f32_e64 %4, %18, |%19|\n"
-        "v_sub_f32_e64 %5, %20, |%21|\n"
+        "v_min_f32_e64 %1, |%4|, |%5|\n"
+        "v_cvt_pknorm_u16_f32 %2, %4, %5\n"
+        "v_min3_f32 %1, %1, |%6|, |%7|\n"
+        "v_cvt_pknorm_u16_f32 %3, %6, %7\n"
+        "v_add_u32_e32 %0, %2, %3\n"
+        "v_min3_f32 %1, %1, |%8|, |%9|\n"
+        "v_cvt_pknorm_u16_f32 %2, %8, %9\n"
+        "v_min3_f32 %1, %1, |%10|, |%11|\n"
+        "v_cvt_pknorm_u16_f32 %3, %10, %11\n"
+        "v_add3_u32 %0, %2, %3, %0\n"
+        : "=&v"(acc), "=&v"(dm), "=&v"(w0), "=&v"(w1)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7));
+}
+__device__ __forceinline__ void vote_slow_close(unsigned& cnt, unsigned& flg, unsigned& acc, float& dm, float x0, float x1,
+                                                float x2, float x3, float x4, float x5, float x6, float x7) {
+    unsigned w0, w1;
+    asm volatile(
         "v_min3_f32 %3, %3, |%6|, |%7|\n"
-        "v_cvt_pknorm_u16_f32 %9, %6, %7\n"
-        "v_sub_f32_e64 %6, %22, |%23|\n"
-        "v_sub_f32_e64 %7, %24, |%25|\n"
-        "v_add3_u32 %2, %8, %9, %2\n"
-        "v_min3_f32 %3, %3, |%4|, |%5|\n"
-        "v_cvt_pknorm_u16_f32 %8, %4, %5\n"
-        "v_min3_f32 %3, %3, |%6|, |%7|\n"
-        "v_cvt_pknorm_u16_f32 %9, %6, %7\n"
+        "v_cvt_pknorm_u16_f32 %4, %6, %7\n"
+        "v_min3_f32 %3, %3, |%8|, |%9|\n"
+        "v_cvt_pknorm_u16_f32 %5, %8, %9\n"
+        "v_add3_u32 %2, %4, %5, %2\n"
+        "v_min3_f32 %3, %3, |%10|, |%11|\n"
+        "v_cvt_pknorm_u16_f32 %4, %10, %11\n"
+        "v_min3_f32 %3, %3, |%12|, |%13|\n"
+        "v_cvt_pknorm_u16_f32 %5, %12, %13\n"
         "v_cmp_nle_f32_e32 vcc, 1.0, %3\n"       // bad = !(dm >= 1)   (NaN cannot occur: |x| of finite x)
-        "v_add3_u32 %2, %8, %9, %2\n"
+        "v_add3_u32 %2, %4, %5, %2\n"
         "s_nop 0\n"
         "v_cndmask_b32_e64 %2, %2, 0, vcc\n"     // the cell's votes, or nothing
         "v_addc_co_u32_e32 %1, vcc, %1, %1, vcc\n"   // flg = 2 flg + bad
         "v_add_u32_e32 %0, %0, %2\n"
-        : "+v"(cnt), "+v"(flg), "+v"(acc), "+v"(dm), "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(w0), "=&v"(w1)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5),
-          "v"(a6), "v"(b6), "v"(a7), "v"(b7)
+        : "+v"(cnt), "+v"(flg), "+v"(acc), "+v"(dm), "=&v"(w0), "=&v"(w1)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7)
         : "vcc");
 }
 constexpr float BAND_CLEAN = 1.0f;     // a cell whose minimum |a'|, |b'| reaches this holds no test inside the band
@@ -1330,6 +1332,14 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
         const int left = (tpad - cg * npx + 31) >> 5;
         const int nti = left < ntiles ? left : ntiles;
         bf16x8 Aa = __builtin_bit_cast(bf16x8, lbase[0]), Ab = __builtin_bit_cast(bf16x8, lbase[64]);
+        // FOLD: the x of the eight tests whose slow operations are still due (see vote_subs), the open cell's votes / minimum.
+        // Before the first step nothing is due: x = -4 counts no vote and flags nothing, the cell it "closes" shifts a zero
+        // into a zero flag word of the last hypothesis tile.
+        float x0 = -4.f, x1 = -4.f, x2 = -4.f, x3 = -4.f, x4 = -4.f, x5 = -4.f, x6 = -4.f, x7 = -4.f, dmo = 3.0e38f;
+        unsigned acc = 0u;
+#define PV_XS x0, x1, x2, x3, x4, x5, x6, x7
+#define PV_LO(v, w) v[0], w[0], v[1], w[1], v[2], w[2], v[3], w[3], v[4], w[4], v[5], w[5], v[6], w[6], v[7], w[7]
+#define PV_HI(v, w) v[8], w[8], v[9], w[9], v[10], w[10], v[11], w[11], v[12], w[12], v[13], w[13], v[14], w[14], v[15], w[15]
         if (NACC == 1) {
             for (int tile = 0; tile < nti; ++tile) {
                 const int nt = tile + 1 < nti ? tile + 1 : tile;
@@ -1337,23 +1347,20 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
                 const bf16x8 Nb = __builtin_bit_cast(bf16x8, lbase[nt * TILE_U4 + 64]);
 #pragma unroll
                 for (int t = 0; t < MH; ++t) {
-                    unsigned acc = 0u;
-                    float dmo = 0.f;
                     const f32x16 va = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aa, B[t], zero, 0, 0, 0);
                     const f32x16 vb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ab, B[t], zero, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("s_nop 11");    // the votes are inline asm: the compiler does not see an MFMA result being read,
-                    __builtin_amdgcn_sched_barrier(0);  // so the wait states are ours to insert (tools/check_mfma_hazard.py)
-                    if (FOLD) {
-                        vote8x_open(acc, dmo, va[0], vb[0], va[1], vb[1], va[2], vb[2], va[3], vb[3], va[4], vb[4], va[5], vb[5],
-                                    va[6], vb[6], va[7], vb[7]);
-                        vote8x_close(cnt[t], flg[t], acc, dmo, va[8], vb[8], va[9], vb[9], va[10], vb[10], va[11], vb[11], va[12],
-                                     vb[12], va[13], vb[13], va[14], vb[14], va[15], vb[15]);
+                    if (FOLD) {   // the previous step's last 15 operations fill the wait for this step's MFMAs
+                        vote_slow_close(cnt[(t + MH - 1) % MH], flg[(t + MH - 1) % MH], acc, dmo, PV_XS);
+                        asm volatile("s_nop 3");   // (the votes are inline asm: the wait states are ours, tools/check_mfma_hazard.py)
+                        vote_subs(PV_XS, PV_LO(va, vb));
+                        vote_slow_open(acc, dmo, PV_XS);
+                        vote_subs(PV_XS, PV_HI(va, vb));
                     } else {
-                        vote8x(cnt[t], dmn[t], va[0], vb[0], va[1], vb[1], va[2], vb[2], va[3], vb[3], va[4], vb[4], va[5], vb[5],
-                               va[6], vb[6], va[7], vb[7]);
-                        vote8x(cnt[t], dmn[t], va[8], vb[8], va[9], vb[9], va[10], vb[10], va[11], vb[11], va[12], vb[12], va[13],
-                               vb[13], va[14], vb[14], va[15], vb[15]);
+                        asm volatile("s_nop 11");
+                        __builtin_amdgcn_sched_barrier(0);
+                        vote8x(cnt[t], dmn[t], PV_LO(va, vb));
+                        vote8x(cnt[t], dmn[t], PV_HI(va, vb));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1369,25 +1376,23 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
             const bf16x8 Nb = __builtin_bit_cast(bf16x8, lbase[nt * TILE_U4 + 64]);
 #pragma unroll
             for (int t = 0; t < MH; ++t) {
-                unsigned acc = 0u;    // FOLD: the open cell's votes / minimum
-                float dmo = 0.f;
                 const f32x16 va2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Aa : Na, B[(t + 1) % MH], zero, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (FOLD)
-                    vote8x_open(acc, dmo, va[0], vb[0], va[1], vb[1], va[2], vb[2], va[3], vb[3], va[4], vb[4], va[5], vb[5],
-                                va[6], vb[6], va[7], vb[7]);
-                else
-                    vote8x(cnt[t], dmn[t], va[0], vb[0], va[1], vb[1], va[2], vb[2], va[3], vb[3], va[4], vb[4], va[5], vb[5],
-                           va[6], vb[6], va[7], vb[7]);
+                if (FOLD) {
+                    vote_slow_close(cnt[(t + MH - 1) % MH], flg[(t + MH - 1) % MH], acc, dmo, PV_XS);
+                    vote_subs(PV_XS, PV_LO(va, vb));
+                } else {
+                    vote8x(cnt[t], dmn[t], PV_LO(va, vb));
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 const f32x16 vb2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t + 1 < MH ? Ab : Nb, B[(t + 1) % MH], zero, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (FOLD)
-                    vote8x_close(cnt[t], flg[t], acc, dmo, va[8], vb[8], va[9], vb[9], va[10], vb[10], va[11], vb[11], va[12],
-                                 vb[12], va[13], vb[13], va[14], vb[14], va[15], vb[15]);
-                else
-                    vote8x(cnt[t], dmn[t], va[8], vb[8], va[9], vb[9], va[10], vb[10], va[11], vb[11], va[12], vb[12], va[13],
-                           vb[13], va[14], vb[14], va[15], vb[15]);
+                if (FOLD) {
+                    vote_slow_open(acc, dmo, PV_XS);
+                    vote_subs(PV_XS, PV_HI(va, vb));
+                } else {
+                    vote8x(cnt[t], dmn[t], PV_HI(va, vb));
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 va = va2;
                 vb = vb2;
@@ -1396,6 +1401,10 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
             Ab = Nb;
         }
         }
+        if (FOLD) vote_slow_close(cnt[MH - 1], flg[MH - 1], acc, dmo, PV_XS);   // the last step's second half
+#undef PV_XS
+#undef PV_LO
+#undef PV_HI
         PV_PHASE(1);
         // ---- clean cells: their counts; flagged cells: into the item's list
         const unsigned all_groups = 1u;  // FOLD = 0: the one cell of the item

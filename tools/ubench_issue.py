@@ -293,6 +293,47 @@ def body_epilogue_approx(mfma, valu):
 
 
 # the same with two fast adds instead of one add3
+# the shipped round-4 epilogue: x = d - |c| (fast class) instead of min3(a, b, 1); per half step (8 tests): 8 sub + 4 min3 + 4 pknorm +
+# 2 add3 (+ 4 to close the cell every second half).  ORDER: where the half's MFMA is issued relative to its operations --
+#   0  MFMA, then the subs and the slow operations interleaved (as shipped: hand-placed distances)
+#   1  the 8 subs of the half, the MFMA, then the 10 slow operations (they only use the port the MFMA leaves free)
+#   2  MFMA, 10 slow operations of the PREVIOUS half's x (kept in 8 more registers), then the subs of this half
+def body_epilogue_sub(mfma, valu, order):
+    lines = []
+    X = ["v78", "v79", "v80", "v81", "v85", "v86", "v87", "v88"]
+    def subs(pd, pc, o, regs):
+        return [f"v_sub_f32_e64 {regs[j]}, v{pd + o + j}, |v{pc + o + j}|" for j in range(8)]
+    def slow(regs, first, close):
+        out = [(f"v_min_f32_e64 v77, |{regs[0]}|, |{regs[1]}|" if first else f"v_min3_f32 v77, v77, |{regs[0]}|, |{regs[1]}|"),
+               f"v_cvt_pknorm_u16_f32 v82, {regs[0]}, {regs[1]}",
+               f"v_min3_f32 v77, v77, |{regs[2]}|, |{regs[3]}|", f"v_cvt_pknorm_u16_f32 v83, {regs[2]}, {regs[3]}",
+               ("v_add_u32_e32 v76, v82, v83" if first else "v_add3_u32 v76, v82, v83, v76"),
+               f"v_min3_f32 v77, v77, |{regs[4]}|, |{regs[5]}|", f"v_cvt_pknorm_u16_f32 v82, {regs[4]}, {regs[5]}",
+               f"v_min3_f32 v77, v77, |{regs[6]}|, |{regs[7]}|", f"v_cvt_pknorm_u16_f32 v83, {regs[6]}, {regs[7]}"]
+        if close:
+            out += ["v_cmp_nle_f32_e32 vcc, 1.0, v77", "v_add3_u32 v76, v82, v83, v76", "s_nop 0", "v_cndmask_b32_e64 v76, v76, 0, vcc",
+                    "v_addc_co_u32_e32 v75, vcc, v75, v75, vcc", "v_add_u32_e32 v74, v74, v76"]
+        else:
+            out += ["v_add3_u32 v76, v82, v83, v76"]
+        return out
+    for q in (0, 1):
+        pd, pc = 10 + 32 * q, 26 + 32 * q
+        for hlf in (0, 1):
+            m = [mfma_pair(1 - q, hlf)] if mfma else []
+            sb = subs(pd, pc, 8 * hlf, X) if valu else []
+            sl = slow(X, hlf == 0, hlf == 1) if valu else []
+            if order == 0:      # shipped: MFMA, 4 subs, then interleaved
+                if valu:
+                    body = sb[:4] + sl[:2] + sb[4:6] + sl[2:4] + sb[6:8] + sl[4:]
+                else:
+                    body = []
+                lines += m + body
+            elif order == 1:
+                lines += sb + m + sl
+            else:
+                lines += m + sl + sb   # (the slow operations read the x of the previous half: same registers, timing only)
+    return lines
+
 KERNEL = r"""
 __global__ __launch_bounds__(256) void {name}(unsigned long long* __restrict__ out, int iters) {{
     extern __shared__ char smem[];
@@ -435,6 +476,13 @@ def main():
             nops = sum(1 for l in lines if l.startswith("v_") and "mfma" not in l)
             src.append(kernel(kn, lines, 88))
             cases.append(f'    {{"{tag} 2 steps{" valu" if va else ""}{" +4mfma" if mf else ""}", {kn}, {nops}, {4 * mf}, 88}},')
+    for order in (0, 1, 2):
+        for mf, va in ((0, 1), (1, 1)):
+            kn = f"k_epi_sub{order}_{mf}{va}"
+            lines = body_epilogue_sub(mf, va, order)
+            nops = sum(1 for l in lines if l.startswith("v_") and "mfma" not in l)
+            src.append(kernel(kn, lines, 96))
+            cases.append(f'    {{"epi_sub order {order} 2 steps{" valu" if va else ""}{" +4mfma" if mf else ""}", {kn}, {nops}, {4 * mf}, 96}},')
     src.append(MAIN % "\n".join(cases))
     out = os.path.join(GEN, "ubench_issue.hip")
     with open(out, "w") as f:
