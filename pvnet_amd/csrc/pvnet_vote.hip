@@ -387,6 +387,18 @@ __device__ __forceinline__ unsigned long long wave_reduce_max(unsigned long long
     return v;
 }
 
+// Workgroup barrier for data shared through LDS ONLY.  __syncthreads() fences every address space: before the barrier each
+// wave waits for ALL its outstanding global operations (s_waitcnt vmcnt(0)) -- in the scoring kernels that means the count
+// atomics of the previous work item.  The scoring kernels' barriers order nothing but the LDS tiles / lists, so they wait for
+// the LDS and scalar counters only.  (Round 4 measured no difference at the benchmark shape, r04c17; a one-item-ahead prefetch
+// of records / B columns / hypotheses built on it hid 1 500 of an item's 4 500 staging cycles and lost them again in the
+// loop and the re-evaluation, r04c18: the kernel is throughput-bound, a workgroup's waits are filled by the other two.)
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // The vector field (and the class logits of the fused arg-max entry) may be float32, float16 or bfloat16 -- what a
 // backbone under autocast emits: elements are widened to float32 where they are read (both conversions are exact), so the
 // result is that of the float32 path on `field.float()` without the copy (786 MB written per batch of 32 otherwise).
@@ -841,7 +853,7 @@ __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
 
         // ---- stage the chunk group's records in LDS (fast mode: expanded-form constants about the image origin)
         const float ox = (float)ctrl[bi * CTRL_STRIDE + C_OX], oy = (float)ctrl[bi * CTRL_STRIDE + C_OY];
-        __syncthreads();  // the previous item's readers are done
+        lds_barrier();  // the previous item's readers are done
         for (int i = threadIdx.x; i < npx; i += 256) {
             const int p = cg * npx + i;
             float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -856,7 +868,7 @@ __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
                 s_b[i] = b;
             }
         }
-        __syncthreads();
+        lds_barrier();
 
         const int g = wave % G, sc = wave / G;
         const int c = cg * S + sc;
@@ -999,7 +1011,7 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
             const uint4 raw = P.hypb[(bk * P.hn_pad + h0 + t * 32 + col) * 2 + half];
             B[t] = __builtin_bit_cast(bf16x8, raw);
         }
-        __syncthreads();  // the previous item's tiles have been consumed
+        lds_barrier();  // the previous item's tiles have been consumed
         for (int i = threadIdx.x; i < npx; i += 256) {  // thread = pixel: expand its record once per workgroup
             const int p = cg * npx + i;
             float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1011,7 +1023,7 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
             a_row(a.x, a.y, a.z, t[0], t[1]);
             a_row(a.w, b.x, b.y, t[64], t[65]);
         }
-        __syncthreads();
+        lds_barrier();
 
         unsigned cnt[MH];  // wrapped vote accumulators (vote8): 16 * ntiles <= 256 votes each
 #pragma unroll
@@ -1068,7 +1080,7 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
         }
     }
     if (TIMED) {
-        __syncthreads();
+        lds_barrier();
         if (threadIdx.x == 0) stamps[2 * blockIdx.x + 1] = (unsigned long long)wall_clock64();
     }
 }
@@ -1279,7 +1291,7 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
         // workgroup-uniform: a new run (the counters hold < 65536 votes per half: a run is cut after 256 items)
         const bool fresh = !RUNS || key != run_key || run_items >= 256;
 
-        __syncthreads();  // the previous item's tiles, raw records and cell list have been consumed
+        lds_barrier();  // the previous item's tiles, raw records and cell list have been consumed
         PV_PHASE(3);
         if (threadIdx.x == 0) s_ncell = 0;
         int tid = threadIdx.x;  // opaque copies of the thread index: what staging and re-evaluation derive from it is
@@ -1319,7 +1331,7 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
             for (int j = 0; j < (4 * MH * 32 + 255) / 256; ++j)
                 if (tid + 256 * j < 4 * MH * 32) s_hyp[tid + 256 * j] = hreg[j];
         }
-        __syncthreads();
+        lds_barrier();
         PV_PHASE(0);
 
         float dmn[MH];      // min |x| of the open cell so far
@@ -1429,7 +1441,7 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
                 if (mask != 0u) s_cells[slot] = (unsigned)(wave * MH * 32 + t * 32 + colx) | ((unsigned)half << 10) | (mask << 11);
             }
         }
-        __syncthreads();
+        lds_barrier();
         PV_PHASE(2);
         // ---- flagged cells, decided by the reference's arithmetic: 16 lanes per cell, one pixel row each
         const int ncell = s_ncell;
@@ -1469,7 +1481,7 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
     }
     if (RUNS && run_key >= 0) flush_counts(run_bk, run_h0);
     if (TIMED) {
-        __syncthreads();
+        lds_barrier();
         PV_PHASE(3);
         if (threadIdx.x == 0) {
             stamps[2 * blockIdx.x + 1] = (unsigned long long)wall_clock64();
