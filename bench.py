@@ -510,10 +510,12 @@ def main(argv=None):
             return voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=SEED0 + i,
                                                  image_offset=rank * BATCH, **mode, **kw)
         st = streams[i % ns]
+        conc = ns > 1   # explicit: batches on other streams are in flight exactly when the region uses several
         with torch.cuda.stream(st):
             if dist is None:
                 return voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=SEED0 + i,
-                                                     image_offset=rank * BATCH, workspace=spaces[i % ns], **mode)
+                                                     image_offset=rank * BATCH, workspace=spaces[i % ns], concurrent=conc,
+                                                     **mode)
             blk, j = bucket["n"] % NBLK, bucket["fill"]
             # the gather that last read this block (NBLK buckets ago) must be complete before a vote overwrites a slot: with
             # four blocks in rotation it long is -- a host-side query, and a device-side wait only if it is not
@@ -521,7 +523,7 @@ def main(argv=None):
                 st.wait_event(sent[blk])
             out = voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=SEED0 + i,
                                                 image_offset=rank * BATCH, out=staging[blk][j], workspace=spaces[i % ns],
-                                                **mode)
+                                                concurrent=conc, **mode)
         bucket["used"].add(i % ns)
         bucket["fill"] += 1
         if bucket["fill"] == G:
@@ -693,9 +695,10 @@ def main(argv=None):
                        "input_sets_cycled": len(sets),
                        "touched_input_bytes": int(len(sets) * compulsory),
                        "streams": nstreams, "prewarm_s": a.prewarm_seconds,
-                       "concurrent_hint": "automatic (pvnet_amd.voting.concurrent_hint): PVNET_F_CONCURRENT on calls whose stream "
-                                          "differs from the previous call's -- i.e. in the multi-stream regions, not in single_stream; "
-                                          "the flag selects a kernel variant, never a result",
+                       "concurrent_hint": "explicit: PVNET_F_CONCURRENT (concurrent=True) on the calls of regions that issue on several "
+                                          "streams, not in single_stream (voting.concurrent_hint consults the stream history only "
+                                          "when a caller passes None); the flag selects a kernel variant -- contiguous item runs + "
+                                          "one accumulator pair -- never a result",
                        "parallelism": f"images sharded over {world} GPU(s); steps issued round-robin on {nstreams} "
                                       f"HIP stream(s) per GPU"},
             "roofline": {"kernel": f"{SCORE_KERNEL}<{L.wg_g * L.hpl // 2}, ...>", "bound": "mfma",

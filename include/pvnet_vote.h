@@ -71,7 +71,7 @@ extern "C" {
                                       than the default; ignored with PVNET_F_LITERAL */
 
 #define PVNET_F_BAND_STATS 128u     /* development aid (exact mode): count the re-evaluated cells / literal tests into the two
-                                      spare words ctrl[b][4], ctrl[b][5] of the workspace (tools/band_stats.py) */
+                                      spare words ctrl[b][4], ctrl[b][5] of the workspace (tools/exact_probe.py) */
 #define PVNET_F_CONCURRENT 256u    /* hint (results do not depend on it): the caller keeps OTHER batches in flight on other streams.
                                       The exact-mode scoring kernel then runs with one accumulator pair (136 instead of 168
                                       VGPRs, ~2 % slower alone), which leaves room on every SIMD for the small stages of the
@@ -191,6 +191,17 @@ int pvnet_vote_v3_stage_repeat(const void* mask, int mask_dtype, const int64_t m
                                float* out_kpts, int32_t* out_status,
                                void* workspace, size_t workspace_bytes, void* stream,
                                int stage, int repeats, float* avg_ms);
+
+/*
+ * pvnet_vote_band_margin (development aid, tools/band_margin.py): how safe is the exact mode's rounding band?  To be called on
+ * the workspace of a completed DEFAULT-mode (exact) call with that call's inlier_thresh.  Every (pixel, hypothesis) test is
+ * re-evaluated on the matrix pipe exactly as the scoring kernel does (x = dt' - |cr'|, trusted there where |x| >= 1) and with
+ * the reference's arithmetic (ransac_voting_kernel.cu:107-125); out_stats [b*vn][4] uint32 on the device:
+ *   [0] float bits of max |x| over the tests whose matrix-pipe vote (x > 0) differs from the reference's -- must be < 1,
+ *   [1] the number of such tests, [2] tests with |x| < 1 (the band as scored), [3] all tests (mod 2^32).
+ */
+int pvnet_vote_band_margin(float thresh, uint32_t* out_stats, int b, int h, int w, int vn, int hn, int max_num,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* Epilogues of the reference's sibling functions.  Both run on the WORKSPACE of a preceding pvnet_vote_v3 call with
  * the same (b,h,w,vn,hn,max_num) on the same stream (they read its compacted pixel lists, hypotheses and counts).

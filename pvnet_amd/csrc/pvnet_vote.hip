@@ -1473,7 +1473,7 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
                 votes += __shfl_xor(votes, 1, 64);
                 if (q == 0 && votes > 0) atomicAdd(P.counts + bk * P.hn_pad + hslice + hl, votes);
             }
-            if (P.flags & PVNET_F_BAND_STATS) {  // development aid: how much was re-evaluated (tools/band_stats.py)
+            if (P.flags & PVNET_F_BAND_STATS) {  // development aid: how much was re-evaluated (tools/exact_probe.py)
                 if (tid2 == 0) atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 4, ncell);
                 if (q == 0 && ntests > 0) atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 5, ntests);
             }
@@ -1512,6 +1512,81 @@ PV_DEF_SCORE_EXACT4(8, 1, 0, 128) PV_DEF_SCORE_EXACT4(8, 2, 0, 160)
 PV_DEF_SCORE_EXACT4(8, 1, 1, 128) PV_DEF_SCORE_EXACT4(8, 2, 1, 160)
 #undef PV_DEF_SCORE_EXACT4
 #undef PV_DEF_SCORE_EXACT
+
+// ------------------------------------------------------------------------------------------------------------
+// Development aid (pvnet_vote_band_margin, tools/band_margin.py): the exactness argument of the exact mode, MEASURED.
+// On the workspace a complete exact-mode call left behind, every (pixel, hypothesis) test is evaluated twice: x = dt' - |cr'|
+// from the very MFMAs, operands and subtraction the scoring kernel uses (same instructions on the same bits: the same x), and
+// inlier_literal() on the raw record.  The scoring kernel trusts x wherever |x| >= 1; so the largest |x| among the tests whose
+// matrix-pipe vote (x > 0) DIFFERS from the literal vote says how close an unflagged disagreement ever comes to the flag
+// threshold: it must stay below 1, and the distance to 1 is the safety margin of the band (band_constant()).
+// out[(image, key-point)][4] (uint32): max |x| over the disagreeing tests (float bits), their number, the tests with |x| < 1
+// (the band as the kernel sees it), all tests (the last two mod 2^32).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void band_margin_kernel(VoteParams P, unsigned* __restrict__ out) {
+    PVNET_SPARE_VGPRS(119);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* s_t = reinterpret_cast<uint4*>(smem);                 // 8 pixel tiles x 2 KB
+    float4* s_raw = reinterpret_cast<float4*>(s_t + 8 * TILE_U4);
+    const int k = blockIdx.x % P.vn, bi = blockIdx.x / P.vn, grp = blockIdx.y;
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+    const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
+    if (P.ctrl[bi * CTRL_STRIDE + C_NCHUNKS] <= 0 || grp * 256 >= tn) return;   // block-uniform
+    const size_t bk = (size_t)bi * P.vn + k;
+    const int tpad = (tn + PAD - 1) / PAD * PAD;
+    const float ox = (float)P.ctrl[bi * CTRL_STRIDE + C_OX], oy = (float)P.ctrl[bi * CTRL_STRIDE + C_OY];
+    const float rho = band_rho(tn);
+    {
+        const int i = threadIdx.x, p = grp * 256 + i;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < tpad) q = P.rec[bk * P.cap + p];
+        s_raw[i] = q;
+        uint4 r0, r1, r2, r3;
+        a_rows_exact(q, P.tau, ox, oy, rho, r0, r1, r2, r3);
+        uint4* t = s_t + (i >> 5) * TILE_U4 + (i & 31) * 2;
+        t[0] = r0;
+        t[1] = r1;
+        t[64] = r2;
+        t[65] = r3;
+    }
+    __syncthreads();
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint4* lbase = s_t + col * 2 + half;
+    const int left = (tpad - grp * 256 + 31) >> 5, nti = left < 8 ? left : 8;
+    float worst = 0.f;
+    unsigned ndis = 0u, nband = 0u, ntest = 0u;
+    for (int ht = wave; ht * 32 < P.hn; ht += 4) {     // hypothesis tiles of this wave
+        const int h = ht * 32 + col;
+        const bf16x8 Bc = __builtin_bit_cast(bf16x8, P.hypb[(bk * P.hn_pad + h) * 2 + half]);
+        const float2 hv = P.hyp[bk * P.hn_pad + h];
+        for (int tile = 0; tile < nti; ++tile) {
+            const bf16x8 Ad = __builtin_bit_cast(bf16x8, lbase[tile * TILE_U4]);
+            const bf16x8 Ac = __builtin_bit_cast(bf16x8, lbase[tile * TILE_U4 + 64]);
+            const f32x16 vd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ad, Bc, zero, 0, 0, 0);
+            const f32x16 vc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac, Bc, zero, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r >> 2) * 8 + half * 4 + (r & 3);
+                const int p = grp * 256 + tile * 32 + row;
+                if (p >= tn || h >= P.hn) continue;    // padding rows / columns: nobody reads their counts
+                const float x = vd[r] - fabsf(vc[r]);  // (one IEEE subtraction, as v_sub_f32 x, d, |c|)
+                const float4 q = s_raw[tile * 32 + row];
+                const bool lit = inlier_literal(q.x, q.y, q.z, q.w, hv.x, hv.y, P.thresh);
+                ++ntest;
+                if (!(fabsf(x) >= BAND_CLEAN)) ++nband;
+                if ((x > 0.f) != lit) {
+                    ++ndis;
+                    worst = fmaxf(worst, fabsf(x));
+                }
+            }
+        }
+    }
+    unsigned* o = out + bk * 4;
+    if (worst > 0.f) atomicMax(o, __float_as_uint(worst));   // (non-negative floats order like their bit patterns)
+    if (ndis) atomicAdd(o + 1, ndis);
+    if (nband) atomicAdd(o + 2, nband);
+    atomicAdd(o + 3, ntest);
+}
 
 // profiling helper of pvnet_vote_v3_stage_repeat: acc[0] += (max end - min start) over the n workgroup slots
 __global__ __launch_bounds__(256) void ts_collect_kernel(const unsigned long long* __restrict__ stamps, int n,
@@ -1980,8 +2055,14 @@ inline void op_voting_grid(int tn, int vn, int hn, int* hslice, int* slices) {
 // benchmark field (tools/exact_probe.py), each flagging its cell.
 float band_constant(float thresh) {
     const double u = ldexp(1.0, -24), t = (double)thresh;
-    const double tau = sqrt(1.0 - t * t) / t;
-    const double k_lit = 10.0 * u * (1.0 + tau * tau) / tau * 1.001;
+    const double tau = sqrt(1.0 - t * t) / t, t0 = acos(t), delta = 10.0 * u;
+    // the reference can disagree with exact arithmetic only for cos(theta) in [t - delta, t + delta]; in units of |d| |u| the
+    // margin is m = tau cos(theta) - sin(theta) = sin(t0 - theta) / cos(t0): its extreme values over that interval, BOTH sides
+    // (the first-order form delta / (sin t0 cos t0) is 1.5 % short on the vote side at thresh 0.99999 and
+    // 20 % at 0.999999, where t0 is no longer large against the interval)
+    const double lo = acos(t + delta < 1.0 ? t + delta : 1.0), hi = acos(t - delta);
+    const double k_side = sin(t0 - lo) > sin(hi - t0) ? sin(t0 - lo) : sin(hi - t0);
+    const double k_lit = k_side / t * 1.001;   // (cos t0 = t)
     const double k_fast = u * (1.0 + tau) * (1.43 * 10.0 + 8.0);
     return (float)(k_lit + k_fast);
 }
@@ -2264,9 +2345,15 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     P.tau = (thresh > 0.f && thresh < 1.f) ? (float)(sqrt(1.0 - (double)thresh * thresh) / (double)thresh) : 0.f;
     // exact mode (the default): matrix-pipe scoring + literal re-evaluation inside the rounding band; needs the B-operand
     // buffer (PVNET_SCORE_MODE=1) and counts by atomics (the re-evaluated cells add theirs the same way)
+    //  without the B-operand buffer (PVNET_SCORE_MODE=0) the default mode cannot run on the matrix pipe: it is
+    // scored literally -- the same counts -- instead of silently falling back to the approximate VALU predicate
+    if (!(flags & (PVNET_F_LITERAL | PVNET_F_APPROX)) && !L.reserved_) flags |= PVNET_F_LITERAL;
     P.exact = (!(flags & (PVNET_F_LITERAL | PVNET_F_APPROX)) && L.reserved_) ? 1 : 0;
     P.kband = P.exact ? band_constant(thresh) : 0.f;
     P.fold1 = P.exact ? band_fold1(tuning().exact_fold, thresh) : 0;
+    //  cells of one pixel tile list a flagged (hypothesis, half-wave) as a tile mask above 11 index bits: 21 tiles;
+    // work items of more tiles (PVNET_SCORE_CHUNK 192 ... 480) use the cell = work item form, which has no such limit
+    if (P.exact && P.fold1 && (L.wg_s * L.chunk) / 32 > 21) P.fold1 = 0;
     if (P.exact) P.atomic_counts = 1;
     P.min_num = min_num; P.max_num = max_num; P.seed = seed; P.image_base = image_base; P.idxs = idxs; P.flags = flags;
     P.ctrl = reinterpret_cast<int32_t*>(base + L.off_ctrl);
@@ -2520,6 +2607,25 @@ int pvnet_vote_distribution(const float* mean, float* out_cov, int b, int h, int
     if (rc) return rc;
     hipLaunchKernelGGL(distribution_kernel, dim3(vn, b), dim3(256), 0, static_cast<hipStream_t>(stream), P, mean,
                        out_cov);
+    PV_LAUNCH_CHECK();
+    return 0;
+}
+
+int pvnet_vote_band_margin(float thresh, uint32_t* out_stats, int b, int h, int w, int vn, int hn, int max_num,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    if (!out_stats) return PVNET_E_BADARG;
+    VoteParams P;
+    int rc = params_for_workspace(P, b, h, w, vn, hn, max_num, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!(thresh >= 1e-3f && thresh < 1.f) || !P.mode) return PVNET_E_UNSUPPORTED;  // the matrix-pipe modes' range
+    P.thresh = thresh;
+    P.tau = (float)(sqrt(1.0 - (double)thresh * thresh) / (double)thresh);
+    P.kband = band_constant(thresh);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PV_HIP(hipMemsetAsync(out_stats, 0, sizeof(uint32_t) * 4 * (size_t)b * vn, s));
+    const size_t lds = 8 * TILE_U4 * sizeof(uint4) + 256 * sizeof(float4);
+    hipLaunchKernelGGL(band_margin_kernel, dim3((unsigned)(b * vn), (unsigned)((P.cap + 255) / 256)), dim3(256), lds, s, P,
+                       reinterpret_cast<unsigned*>(out_stats));
     PV_LAUNCH_CHECK();
     return 0;
 }

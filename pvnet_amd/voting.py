@@ -97,6 +97,8 @@ def load_library() -> C.CDLL:
     lib.pvnet_vote_confidence.argtypes = [f32p, C.c_float, f32p, C.c_uint32] + ws_tail
     lib.pvnet_vote_distribution.restype = C.c_int
     lib.pvnet_vote_distribution.argtypes = [f32p, f32p] + ws_tail
+    lib.pvnet_vote_band_margin.restype = C.c_int
+    lib.pvnet_vote_band_margin.argtypes = [C.c_float, C.c_void_p] + ws_tail
     lib.pvnet_vote_tuning_reload.restype = None
     lib.pvnet_vote_tuning_reload.argtypes = []
     if lib.pvnet_vote_abi_version() != 6:
@@ -202,6 +204,17 @@ def mode_flags(literal: bool, approx: bool, inlier_thresh: float) -> int:
 
 
 _last_stream = {}  # device index -> the stream of the previous voting call on that device
+
+
+def reset_concurrent_hint(dev=None):
+    """forget the stream history ``concurrent_hint`` keeps (all devices, or one): the next call with ``concurrent=None`` on a
+    device counts as its first.  For callers that switch streams once (a warm-up on a side stream, a profiler) and do not want
+    the one call after the switch to run the multi-batch variant; ``concurrent=False`` / ``True`` never consult the history."""
+    if dev is None:
+        _last_stream.clear()
+    else:
+        dev = torch.device(dev)
+        _last_stream.pop(dev.index if dev.index is not None else torch.cuda.current_device(), None)
 
 
 def concurrent_hint(dev, concurrent: Optional[bool]) -> int:
@@ -318,17 +331,39 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
     if return_debug:
         d = _debug_views(ws, L)
         d["literal"] = bool(literal)
-        d["mode"] = "literal" if literal else ("approx" if approx else "exact")
+        # what the library really ran: without the matrix-pipe buffers (PVNET_SCORE_MODE=0) the default mode is scored literally
+        d["mode"] = "literal" if (literal or (not approx and not L.reserved_)) else ("approx" if approx else "exact")
         d["concurrent"] = bool(flags & F_CONCURRENT)
         if band_stats:  # (cells re-evaluated, literal tests made) of this call; synchronises
             d["band_stats"] = tuple(int(x) for x in d["ctrl"][b, 4:6].tolist())
         d["status"] = status
         d["seed"] = seed
         d["workspace"] = ws
+        d["max_num"] = max_num
         extras.append(d)
     if stage_times:
         extras.append(times)
     return (out, *extras) if extras else out
+
+
+def band_margin(dbg, inlier_thresh):
+    """development aid: the measured safety margin of the exact mode's rounding band on the workspace of a completed
+    default-mode call (``dbg`` = its ``return_debug`` dict; same ``inlier_thresh``): every test re-evaluated on the matrix
+    pipe as the scoring kernel does it and with the reference's arithmetic.  Returns a dict: ``worst`` = the largest |x|
+    among the tests whose matrix-pipe vote differs from the reference's (the kernel trusts x only where |x| >= 1: must be
+    < 1), ``disagree`` their number, ``band`` the tests with |x| < 1, ``tests``.  Synchronises."""
+    L, ws = dbg["layout"], dbg["workspace"]
+    dev = ws.device
+    out = torch.zeros((L.b * L.vn, 4), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load_library().pvnet_vote_band_margin(
+            C.c_float(inlier_thresh), C.c_void_p(out.data_ptr()), L.b, L.h, L.w, L.vn, L.hn, int(dbg["max_num"]),
+            C.c_void_p(ws.data_ptr()), C.c_size_t(L.total_bytes), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+            "pvnet_vote_band_margin")
+    o = out.cpu()
+    u = o.to(torch.int64) & 0xFFFFFFFF
+    return {"worst": float(o[:, 0].contiguous().view(torch.float32).max()), "disagree": int(u[:, 1].sum()),
+            "band": int(u[:, 2].sum()), "tests": int(u[:, 3].sum())}
 
 
 def stage_repeat_ms(mask, vertex, round_hyp_num, inlier_thresh=0.999, min_num=5, max_num=30000, *, stage="score",

@@ -202,3 +202,77 @@ def test_concurrent_hint_is_result_neutral_and_follows_the_streams():
         torch.cuda.synchronize()
         assert torch.equal(out, ref)
     assert seen[1:] == [False, True, True, False]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hpl,chunk,hn", [(8, 384, 1024), (2, 224, 128), (8, 480, 1024)])
+def test_items_of_more_than_21_pixel_tiles_count_like_literal(hpl, chunk, hn, monkeypatch):
+    """cells of one pixel tile list a flagged (hypothesis, half-wave) as a tile mask above 11 index bits -- 21 tiles.
+    Layouts with larger work items (24, 28, 30 tiles here) fall back to the cell = work item form instead of losing flags."""
+    m, v, _ = batch(2, 77, 480, 640, 45)
+    _, dl = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=0.999, seed=4, literal=True, return_debug=True)
+    cl = dl["counts"].clone()
+    monkeypatch.setenv("PVNET_SCORE_HPL", str(hpl))
+    monkeypatch.setenv("PVNET_SCORE_CHUNK", str(chunk))
+    voting.reload_tuning()
+    try:
+        for conc in (False, True):
+            _, de = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=0.999, seed=4, return_debug=True, concurrent=conc)
+            L = de["layout"]
+            assert L.wg_s * L.chunk // 32 > 21
+            assert torch.equal(de["counts"], cl), (hpl, chunk, hn, conc)
+    finally:
+        monkeypatch.delenv("PVNET_SCORE_HPL")
+        monkeypatch.delenv("PVNET_SCORE_CHUNK")
+        voting.reload_tuning()
+
+
+@pytest.mark.gpu
+def test_default_mode_without_the_matrix_pipe_buffers_is_scored_literally(monkeypatch):
+    """PVNET_SCORE_MODE=0 leaves no B-operand buffer; the default mode must then give the reference's counts by
+    literal scoring (and say so), not the approximate VALU predicate's."""
+    m, v, _ = batch(2, 91, 240, 320, 24)
+    _, dl = voting.ransac_voting_layer_v3(m, v, 256, inlier_thresh=0.99, seed=8, literal=True, return_debug=True)
+    cl = dl["counts"].clone()
+    monkeypatch.setenv("PVNET_SCORE_MODE", "0")
+    voting.reload_tuning()
+    try:
+        _, d = voting.ransac_voting_layer_v3(m, v, 256, inlier_thresh=0.99, seed=8, return_debug=True)
+        assert d["mode"] == "literal" and torch.equal(d["counts"], cl)
+        _, da = voting.ransac_voting_layer_v3(m, v, 256, inlier_thresh=0.99, seed=8, approx=True, return_debug=True)
+        assert da["mode"] == "approx"
+    finally:
+        monkeypatch.delenv("PVNET_SCORE_MODE")
+        voting.reload_tuning()
+    _, d = voting.ransac_voting_layer_v3(m, v, 256, inlier_thresh=0.99, seed=8, return_debug=True)
+    assert d["mode"] == "exact" and torch.equal(d["counts"], cl)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("thresh", [0.99999, 0.999999])
+def test_thresholds_next_to_one(thresh):
+    """the band is computed on both sides of the threshold angle (band_constant): at 0.99999 / 0.999999 the
+    first-order form was 1.5 % / 20 % short on the vote side.  Counts equal literal's; the measured margin stays below 1."""
+    m, v, _ = batch(4, 611, 480, 640, 40, noise=False)   # a clean field: most tests sit right at such a threshold
+    _, dl = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=thresh, seed=3, literal=True, return_debug=True)
+    cl = dl["counts"].clone()
+    _, de = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=thresh, seed=3, return_debug=True)
+    assert de["mode"] == "exact" and torch.equal(de["counts"], cl)
+    r = voting.band_margin(de, thresh)
+    assert r["tests"] > 1e8 and r["worst"] < 0.5, r
+
+
+@pytest.mark.gpu
+def test_band_margin_is_measured_not_assumed():
+    """on the benchmark field and on large objects, thresholds 0.9 / 0.99 / 0.999, every test is evaluated on
+    the matrix pipe as the scoring kernel does and with the reference's arithmetic: the largest |x| of a test on which the two
+    disagree must stay far below 1 (where the kernel stops trusting x) -- tools/band_margin.py, profiles/r04_band_margin.txt."""
+    worst, tests = 0.0, 0
+    for b, radius in ((8, 40), (2, 97)):
+        m, v, _ = batch(b, 4242, 480, 640, radius)
+        for thresh in (0.9, 0.99, 0.999):
+            _, d = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=thresh, seed=1, return_debug=True)
+            r = voting.band_margin(d, thresh)
+            assert r["band"] > 0 and r["tests"] == int(d["tn"][:b].sum()) * 9 * 1024
+            worst, tests = max(worst, r["worst"]), tests + r["tests"]
+    assert tests > 2e9 and worst < 0.5, (tests, worst)
