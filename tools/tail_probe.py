@@ -14,7 +14,8 @@ from pvnet_amd import synth, voting  # noqa: E402
 approx = "--approx" in sys.argv
 dev = torch.device("cuda:0")
 lib = voting.load_library()
-mask, planar, _ = synth.make_batch(32, first_index=0, radius=40, noise=True, background="normal")
+first = int(os.environ.get("PROBE_FIRST", "0"))  # first image index of the synthetic batch (which images land on which XCD)
+mask, planar, _ = synth.make_batch(32, first_index=first, radius=40, noise=True, background="normal")
 m = torch.from_numpy(mask).to(dev)
 v = synth.planar_to_vertex_view(torch.from_numpy(planar).to(dev))
 b, h, w, vn, hn = 32, 480, 640, 9, 1024
@@ -54,3 +55,7 @@ jj = np.arange(grid) // 8
 for lo_j in range(0, grid // 8, 32):
     sel = (jj >= lo_j) & (jj < lo_j + 32)
     print(f"  j {lo_j:3d}..{lo_j + 31:3d}: start {start[sel].mean():6.1f}  lifetime {life[sel].mean():6.1f}  end {end[sel].mean():6.1f} (max {end[sel].max():6.1f})")
+# per XCD (workgroup index % 8): when its last workgroup ended, and the sum of its workgroups' lifetimes
+for x in range(8):
+    sel = (np.arange(grid) % 8) == x
+    print(f"  XCD {x}: last end {end[sel].max():6.1f} us   sum of lifetimes {life[sel].sum():8.0f} us   mean lifetime {life[sel].mean():5.1f} us")
