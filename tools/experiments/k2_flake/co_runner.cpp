@@ -40,12 +40,15 @@ int main(int argc, char** argv) {
     if (hipModuleGetFunction(&fn, mod, "_Z14compact_kernelILi1EEv6Params") != hipSuccess) { printf("no function\n"); return 1; }
     std::vector<float4> rec((size_t)b * vn * cap);
     int badruns = 0, reps = argc > 2 ? atoi(argv[2]) : 200;
+    // round 4: threads per workgroup, z extent of the grid and dynamic LDS of the variant (k2_repro_r4.hip: -DNT / -DDUAL / -DDYNLDS)
+    const int threads = argc > 3 ? atoi(argv[3]) : 256, gz = argc > 4 ? atoi(argv[4]) : vn, lds = argc > 5 ? atoi(argv[5]) : 0;
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     size_t psize = sizeof(P);
     void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &P, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
     long total_bad = 0;
     for (int rep = 0; rep < reps; ++rep) {
         (void)hipMemset(drec, 0xFF, rec.size() * 16);
-        if (hipModuleLaunchKernel(fn, nseg, b, vn, 256, 1, 1, 0, 0, nullptr, cfg) != hipSuccess) { printf("launch failed\n"); return 1; }
+        if (hipModuleLaunchKernel(fn, nseg, b, gz, threads, 1, 1, lds, 0, nullptr, cfg) != hipSuccess) { printf("launch failed\n"); return 1; }
         (void)hipMemcpy(rec.data(), drec, rec.size() * 16, hipMemcpyDeviceToHost);
         int bad = 0;
         for (int bi = 0; bi < b; ++bi)
