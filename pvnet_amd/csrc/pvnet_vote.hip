@@ -310,9 +310,18 @@ __device__ __forceinline__ void b_col(float x, float y, uint4& lo, uint4& hi) {
 // hypothesis generation reads it -- a 1e-7 direction paired with a 1e12 one has a determinant far above ITS gate.)
 constexpr float BAND_TARGET = 0.9f;             // |s sigma m| inside the band (proof obligation: < 1 with the float roundings of the scales)
 constexpr float BAND_FAR = 0x1p61f;             // beyond this the reference's float32 squares may overflow
-__device__ __forceinline__ float band_rho(int tn) {  // the length scale that splits |d| <= (R + rho)(1 + r / rho)
-    const float r = __builtin_sqrtf(0.3183f * (float)tn);  // radius of a disk of tn pixels
+// the length scale that splits |d| <= (R + rho)(1 + r / rho), R = |h - o|, r = |c - o|.  Round 4: the origin o is an estimate of
+// the KEY-POINT (per image and key-point, band_origin() in the hypothesis kernel), no longer the image's median pixel: most
+// hypotheses then have a small R and the bound is ~(rho + r) for them instead of ~3 |d|.  Simulated on the benchmark field
+// (profiles/r04_band_origin_study.txt): 25 % fewer tests inside the band; 0.6 of the radius of a disk of tn pixels is the best
+// rho for that origin (0.4 .. 0.8 within 2 %).  Any o and any rho > 0 keep the exactness argument: they only move the bound.
+__device__ __forceinline__ float band_rho(int tn) {
+    const float r = 0.6f * __builtin_sqrtf(0.3183f * (float)tn);
     return r < 8.f ? 8.f : r;
+}
+// origin of the exact mode's band per (image, key-point): int32 [b][vn][2] behind the ctrl rows (integer: pixel - origin is exact)
+__device__ __forceinline__ int32_t* band_origin_ptr(const VoteParams& P, size_t bk) {
+    return P.ctrl + (size_t)(P.b + 1) * CTRL_STRIDE + 2 * bk;
 }
 __device__ __forceinline__ void b_col_exact(float hxo, float hyo, float rho, float kband, uint4& lo, uint4& hi) {
     const float R = __builtin_sqrtf(fmaf(hxo, hxo, hyo * hyo)) * 1.000001f;
@@ -728,9 +737,9 @@ __device__ __forceinline__ void plan_image(const VoteParams& P, int bi) {
 // ------------------------------------------------------------------------------------------------------------
 // K3: hypotheses                                               (ransac_voting_gpu.py:547,554; kernel.cu:11-49)
 // ------------------------------------------------------------------------------------------------------------
-template <bool LITERAL>
-__global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
-    PVNET_SPARE_VGPRS(39);
+template <bool LITERAL>   // (amdgpu_num_vgpr: 40 usable of the 48 allocated -- the backend doubles the literal on this target)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(20))) void hypothesis_kernel(VoteParams P) {
+    PVNET_SPARE_VGPRS(47);
     small_stage_prio();
     // Workgroups go to the 8 XCDs round-robin by linear id; every block of image bi is placed on XCD bi % 8 so that
     // the two random 16-byte record reads per hypothesis (several per 128-byte line of the image's records) hit
@@ -747,10 +756,20 @@ __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
     const int i = blk * 256 + threadIdx.x;
     const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
     const bool live = P.ctrl[bi * CTRL_STRIDE + C_TN0] >= P.min_num && tn > 0;  // gates of :531-534
-    if (i < P.hn * P.vn) {
-    const int h = i / P.vn, k = i - h * P.vn;
-    float hx = 0.f, hy = 0.f;
-    if (live) {
+    // Exact mode: the origin of the band per key-point (band_rho()).  Every block of the image works it out for itself (it
+    // needs it before it writes its first B column): eight candidate intersections per key-point from FIXED pixel pairs
+    // spread over the foreground list (records t and t + tn / 2), their component-wise median, rounded to integers.  It only
+    // scales the band -- no result depends on it -- so a bad estimate (fewer than three usable candidates: the image's median
+    // pixel instead) costs re-evaluations, never correctness.
+    constexpr int NCAND = 8, KP_MAX = 32;
+    __shared__ float s_cand[KP_MAX * NCAND * 2];
+    __shared__ int s_org[KP_MAX * 2];
+    __shared__ float s_med[KP_MAX * 2];
+    const bool kp_origin = !LITERAL && P.mode && P.exact && P.vn <= KP_MAX;   // block-uniform
+    // the thread's own hypothesis: its two records are requested NOW, so that they travel while the origin is worked out
+    const int hh = i / P.vn, hk = i - hh * P.vn;
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+    if (live && i < P.hn * P.vn) {
         int t0, t1;
         if (P.idxs) {
             t0 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2];
@@ -762,8 +781,90 @@ __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
             t0 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u), (uint32_t)tn);
             t1 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u + 1u), (uint32_t)tn);
         }
-        const float4 q0 = P.rec[((size_t)bi * P.vn + k) * P.cap + t0];  // (x, y, direction) of the two pixels
-        const float4 q1 = P.rec[((size_t)bi * P.vn + k) * P.cap + t1];
+        q0 = P.rec[((size_t)bi * P.vn + hk) * P.cap + t0];  // (x, y, direction) of the two pixels
+        q1 = P.rec[((size_t)bi * P.vn + hk) * P.cap + t1];
+    }
+    if (kp_origin) {
+        int pm = 0;
+        if (live) pm = P.pix[(size_t)bi * P.cap + tn / 2];
+        if ((int)threadIdx.x < P.vn * NCAND) {
+            const int kk = threadIdx.x / NCAND, j = threadIdx.x % NCAND;
+            float cx = __uint_as_float(0x7FC00000u), cy = cx;   // NaN = no candidate
+            if (live) {
+                const int ta = (int)(((long long)(2 * j + 1) * tn) >> 4);
+                int tb = ta + tn / 2;
+                tb = tb >= tn ? tb - tn : tb;
+                const float4 q0 = P.rec[((size_t)bi * P.vn + kk) * P.cap + ta], q1 = P.rec[((size_t)bi * P.vn + kk) * P.cap + tb];
+                float hx0, hy0;
+                hyp_intersect(q0.z, q0.w, q0.x, q0.y, q1.z, q1.w, q1.x, q1.y, hx0, hy0);
+                if ((hx0 != 0.f || hy0 != 0.f) && fabsf(hx0) < 1048576.f && fabsf(hy0) < 1048576.f) { cx = hx0; cy = hy0; }
+            }
+            s_cand[threadIdx.x * 2] = cx;
+            s_cand[threadIdx.x * 2 + 1] = cy;
+        }
+        __syncthreads();
+        // median by rank, one thread per candidate (no arrays in registers: this kernel's 40-VGPR allocation is what lets two of
+        // its workgroups start beside a resident scoring kernel): candidate j is the median of a coordinate when n / 2 valid
+        // ones sort before it (NaN compares false: never counted, never the median)
+        const int kk = threadIdx.x / NCAND, j = threadIdx.x % NCAND;
+        const bool mine = (int)threadIdx.x < P.vn * NCAND;
+        const float* cand = s_cand + (mine ? kk : 0) * NCAND * 2;
+        int n = 0;
+        if (mine) {
+            int rx = 0, ry = 0;
+            const float vx = cand[2 * j], vy = cand[2 * j + 1];
+            for (int m2 = 0; m2 < NCAND; ++m2) {
+                const float ux = cand[2 * m2], uy = cand[2 * m2 + 1];
+                n += ux == ux ? 1 : 0;
+                rx += (ux < vx || (ux == vx && m2 < j)) ? 1 : 0;
+                ry += (uy < vy || (uy == vy && m2 < j)) ? 1 : 0;
+            }
+            if (vx == vx && rx == n / 2) s_med[kk * 2] = vx;
+            if (vy == vy && ry == n / 2) s_med[kk * 2 + 1] = vy;
+        }
+        __syncthreads();
+        if (mine && n >= 3) {   // the candidates' spread: the median of their (Chebyshev) distances from the median point
+            const float mx = s_med[kk * 2], my = s_med[kk * 2 + 1];
+            const float dj = fmaxf(fabsf(cand[2 * j] - mx), fabsf(cand[2 * j + 1] - my));
+            int rank = 0;
+            for (int m2 = 0; m2 < NCAND; ++m2) {
+                const float d2 = fmaxf(fabsf(cand[2 * m2] - mx), fabsf(cand[2 * m2 + 1] - my));
+                rank += (d2 < dj || (d2 == dj && m2 < j)) ? 1 : 0;
+            }
+            if (dj == dj && rank == n / 2) {
+                // Is the key-point a better origin than the median pixel?  With hypotheses spread S about it, at distance D from
+                // the object (radius Ro), the band bound (R + rho)(1 + r / rho) is about (S + rho)(1 + (D + Ro) / rho) there and
+                // (D + S + rho)(1 + Ro / rho) about the median pixel: take the smaller.  (Fields whose lines are nearly parallel
+                // scatter their intersections over 1e5 px: S ~ D -- the median pixel; the benchmark field: S ~ 3 px -- the key-point.)
+                const float rho = band_rho(tn), ro = rho * (1.f / 0.6f);
+                const float dist = fmaxf(fabsf(mx - (float)(pm % P.w)), fabsf(my - (float)(pm / P.w)));
+                const bool kp = (dj + rho) * (1.f + (dist + ro) / rho) < (dist + dj + rho) * (1.f + ro / rho);
+                s_org[kk * 2] = kp ? (int)rintf(mx) : pm % P.w;
+                s_org[kk * 2 + 1] = kp ? (int)rintf(my) : pm / P.w;
+            }
+        } else if (mine && j == 0) {   // fewer than three usable candidates
+            s_org[kk * 2] = pm % P.w;
+            s_org[kk * 2 + 1] = pm / P.w;
+        }
+        __syncthreads();
+        if (blk == 0 && (int)threadIdx.x < P.vn) {   // for the scoring kernel's staging (a_rows_exact)
+            int32_t* o = band_origin_ptr(P, (size_t)bi * P.vn + threadIdx.x);
+            o[0] = s_org[threadIdx.x * 2];
+            o[1] = s_org[threadIdx.x * 2 + 1];
+        }
+    } else if (!LITERAL && P.mode && P.exact && blk == 0) {   // more than KP_MAX key-points: the image's median pixel for all of them
+        int pm = 0;
+        if (live) pm = P.pix[(size_t)bi * P.cap + tn / 2];
+        for (int kk = threadIdx.x; kk < P.vn; kk += 256) {
+            int32_t* o = band_origin_ptr(P, (size_t)bi * P.vn + kk);
+            o[0] = pm % P.w;
+            o[1] = pm / P.w;
+        }
+    }
+    if (i < P.hn * P.vn) {
+    const int h = hh, k = hk;
+    float hx = 0.f, hy = 0.f;
+    if (live) {
         const float2 d0 = rec_dir(q0), d1 = rec_dir(q1);
         hyp_intersect(d0.x, d0.y, q0.x, q0.y, d1.x, d1.y, q1.x, q1.y, hx, hy);
     }
@@ -771,7 +872,10 @@ __global__ __launch_bounds__(256) void hypothesis_kernel(VoteParams P) {
     if (P.atomic_counts) P.counts[((size_t)bi * P.vn + k) * P.hn_pad + h] = 0;  // K4 accumulates into it
     if (!LITERAL && P.mode) {  // the same hypothesis about the image's local origin, as a bf16x3 B operand column
         float ox = 0.f, oy = 0.f;
-        if (live) {
+        if (kp_origin) {
+            ox = (float)s_org[k * 2];
+            oy = (float)s_org[k * 2 + 1];
+        } else if (live) {
             const int pm = P.pix[(size_t)bi * P.cap + tn / 2];  // the origin plan_image() records for this image
             ox = (float)(pm % P.w);
             oy = (float)(pm / P.w);
@@ -1281,9 +1385,10 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
         const int4 desc = P.items[item];
         const int bi = desc.x, k = desc.y, cg = desc.z, hq = desc.w;
         const int tn = ctrl[bi * CTRL_STRIDE + C_TN];
-        const float ox = (float)ctrl[bi * CTRL_STRIDE + C_OX], oy = (float)ctrl[bi * CTRL_STRIDE + C_OY];
         const float rho = band_rho(tn);
         const size_t bk = (size_t)bi * P.vn + k;
+        const int32_t* const org = band_origin_ptr(P, bk);   // the band's origin for this key-point (hypothesis_kernel)
+        const float ox = (float)org[0], oy = (float)org[1];
         const int tpad = (tn + PAD - 1) / PAD * PAD;
         const int hslice = hq * 4 * MH * 32;            // first hypothesis of this work item
         const int h0 = hslice + wave * MH * 32;         // this wave's first hypothesis
@@ -1534,7 +1639,8 @@ __global__ __launch_bounds__(256) void band_margin_kernel(VoteParams P, unsigned
     if (P.ctrl[bi * CTRL_STRIDE + C_NCHUNKS] <= 0 || grp * 256 >= tn) return;   // block-uniform
     const size_t bk = (size_t)bi * P.vn + k;
     const int tpad = (tn + PAD - 1) / PAD * PAD;
-    const float ox = (float)P.ctrl[bi * CTRL_STRIDE + C_OX], oy = (float)P.ctrl[bi * CTRL_STRIDE + C_OY];
+    const int32_t* const org = band_origin_ptr(P, bk);
+    const float ox = (float)org[0], oy = (float)org[1];
     const float rho = band_rho(tn);
     {
         const int i = threadIdx.x, p = grp * 256 + i;
@@ -2431,7 +2537,8 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     L->nseg = (L->words + SEG_WORDS - 1) / SEG_WORDS;
-    L->off_ctrl = take(sizeof(int32_t) * CTRL_STRIDE * (size_t)(b + 1));
+    // ctrl rows [b + 1][8], then the exact mode's band origins int32 [b][vn][2] (band_origin_ptr())
+    L->off_ctrl = take(sizeof(int32_t) * (CTRL_STRIDE * (size_t)(b + 1) + 2 * (size_t)b * vn));
     // [2][b][nseg] int32 (the second array holds the mask's segment counts; the first is unused since round 2), then,
     // when thinning is possible (max_num < h*w), the segments' cumulative histograms uint16 [b][nseg][THIN_BINS]
     L->off_seg = take(align_up(sizeof(int32_t) * 2 * (size_t)b * L->nseg, 16) +
