@@ -182,6 +182,8 @@ def _debug_views(ws: torch.Tensor, L: Layout):
         hyp=view(L.off_hyp, 8 * b * vn * hp, torch.float32, (b, vn, hp, 2))[:, :, :L.hn],
         counts=view(L.off_counts, 4 * b * vn * hp, torch.int32, (b, vn, hp))[:, :, :L.hn],
         win=view(L.off_win, 8 * b * vn, torch.int32, (b, vn, 2)),
+        # exact mode: the origin of the rounding band per (image, key-point), behind the ctrl rows (band_origin_ptr())
+        band_origin=view(L.off_ctrl + 4 * 8 * (b + 1), 8 * b * vn, torch.int32, (b, vn, 2)),
     )
 
 

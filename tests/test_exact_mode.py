@@ -276,3 +276,49 @@ def test_band_margin_is_measured_not_assumed():
             assert r["band"] > 0 and r["tests"] == int(d["tn"][:b].sum()) * 9 * 1024
             worst, tests = max(worst, r["worst"]), tests + r["tests"]
     assert tests > 2e9 and worst < 0.5, (tests, worst)
+
+
+@pytest.mark.gpu
+def test_band_origin_is_the_keypoint_where_that_helps_and_never_matters_for_the_result():
+    """Round 4: the exact mode's band is centred on an estimate of the key-point (hypothesis kernel) unless the candidate
+    intersections scatter (near-parallel fields): the origin moves the number of re-evaluated cells, never a count."""
+    mask, planar, kpts = synth.make_batch(3, first_index=700, h=480, w=640, radius=40, noise=True, background="normal")
+    m = torch.from_numpy(mask).to(dev())
+    v = synth.planar_to_vertex_view(torch.from_numpy(planar).to(dev()))
+    _, dl = voting.ransac_voting_layer_v3(m, v, 512, inlier_thresh=0.999, seed=2, literal=True, return_debug=True)
+    cl = dl["counts"].clone()
+    _, de = voting.ransac_voting_layer_v3(m, v, 512, inlier_thresh=0.999, seed=2, return_debug=True, band_stats=True)
+    assert torch.equal(de["counts"], cl)
+    org = de["band_origin"].cpu().numpy().astype(np.float64)[:, :, :2]
+    assert np.abs(org - kpts[:, :, :2]).max() < 6.0          # within a few pixels of the true key-points on this field
+    cells_kp = de["band_stats"][0]
+    # a field whose lines are nearly parallel: intersections 1e4 .. 1e6 px away, scattered -> the median pixel is kept
+    squeezed = planar.copy()
+    squeezed[:, 1::2] *= 1e-4
+    v2 = synth.planar_to_vertex_view(torch.from_numpy(squeezed).to(dev()))
+    _, dl2 = voting.ransac_voting_layer_v3(m, v2, 512, inlier_thresh=0.999, seed=2, literal=True, return_debug=True)
+    cl2 = dl2["counts"].clone()
+    _, de2 = voting.ransac_voting_layer_v3(m, v2, 512, inlier_thresh=0.999, seed=2, return_debug=True, band_stats=True)
+    assert torch.equal(de2["counts"], cl2)
+    tests = int(de2["tn"][:3].sum()) * 9 * 512
+    assert de2["band_stats"][1] < 1e-3 * tests, de2["band_stats"]   # (a far-away origin would re-evaluate most of them)
+    assert cells_kp > 0
+
+
+@pytest.mark.gpu
+def test_more_than_32_keypoints_use_the_image_origin():
+    """the key-point origin is worked out for up to 32 key-points per image; beyond that the median pixel serves all of them"""
+    rng = np.random.default_rng(5)
+    h, w, vn = 120, 160, 40
+    mask = np.zeros((1, h, w), np.int64)
+    mask[0] = synth.disk_mask(h, w, 80, 60, 22)
+    kp = np.stack([rng.uniform(40, 120, vn), rng.uniform(30, 90, vn)], 1)
+    planar = synth.add_noise(synth.field_from_keypoints(mask[0].astype(bool), kp), mask[0].astype(bool), rng)[None]
+    m = torch.from_numpy(mask).to(dev())
+    v = synth.planar_to_vertex_view(torch.from_numpy(planar).to(dev()))
+    _, dl = voting.ransac_voting_layer_v3(m, v, 256, inlier_thresh=0.99, seed=1, literal=True, return_debug=True)
+    cl = dl["counts"].clone()
+    _, de = voting.ransac_voting_layer_v3(m, v, 256, inlier_thresh=0.99, seed=1, return_debug=True)
+    assert torch.equal(de["counts"], cl)
+    org = de["band_origin"][0].cpu().numpy()
+    assert (org == org[0]).all()   # one origin for all 40
