@@ -254,12 +254,14 @@ class GpuSampler:
             time.sleep(self.period)
 
     def __enter__(self):
-        self._thread.start()
+        if os.environ.get("BENCH_NO_SAMPLER") != "1":   # (development A/B: does reading the sensors disturb short regions?)
+            self._thread.start()
         return self
 
     def __exit__(self, *exc):
         self._stop.set()
-        self._thread.join(timeout=1.0)
+        if self._thread.is_alive():
+            self._thread.join(timeout=1.0)
 
     def summary(self):
         def stat(xs, scale):
@@ -585,7 +587,7 @@ def main(argv=None):
     t_pre = time.perf_counter()                      # device pre-warm (untimed, reported in config.prewarm_s)
     i_pre = 0
     while time.perf_counter() - t_pre < a.prewarm_seconds:
-        for _ in range(20):  # voting only: a time-bounded loop must not issue collectives (ranks would disagree on the count)
+        for _ in range(200):  # voting only: a time-bounded loop must not issue collectives (ranks would disagree on the count)
             m, v, _, _ = sets[i_pre % len(sets)]
             with torch.cuda.stream(streams[i_pre % nstreams]):
                 voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=i_pre, image_offset=rank * BATCH)
@@ -596,8 +598,16 @@ def main(argv=None):
     # every synchronise) still saw the clock ramp (188.9 k against 198 k for the other fourteen).  One more region of the very
     # form that is timed -- warm-up, fence, K steps, fence -- runs first and is NOT recorded: the recorded ones start from the
     # state a steady caller is in.  (Not a change of what a region is: W untimed steps, exactly K timed steps, fences around.)
-    regions(nstreams, mode=MAIN, n=2 if a.steps < 200 else 1)
+    # (round 4, r04c36-38: with K = 20 the rate climbs over the first six regions -- 205 k -> 219 k -- whatever the length of the
+    # pre-warm loop and with or without the sensor thread: twelve unrecorded regions)
+    # (the sensor thread is created and started BEFORE the unrecorded regions -- r04c39: whatever its start disturbs, the
+    # regions right after it were 5 % low although the unrecorded ones before it had settled -- and its samples are cleared
+    # when the recorded regions begin)
     with GpuSampler(local) as sampler:
+        pre = regions(nstreams, mode=MAIN, n=int(os.environ.get("BENCH_UNRECORDED", "12")) if a.steps < 200 else 1)
+        if os.environ.get("BENCH_SHOW_UNRECORDED") == "1":
+            print("unrecorded regions (k votings/s):", [round(world * BATCH * a.steps / r[0] / 1e3, 1) for r in pre], file=sys.stderr)
+        sampler.samples.clear()
         runs = regions(nstreams, mode=MAIN)          # the headline: R regions of K steps, independent batches on S streams
     dts = [r[0] for r in runs]
     dt = median(dts)
@@ -671,8 +681,9 @@ def main(argv=None):
             "regions": {"runs": len(dts), "reported": "median", "min": min(rates), "max": max(rates),
                         "spread": (max(rates) - min(rates)) / votings_per_s, "values": rates,
                         "note": "the timed region (fence, exactly K steps, fence; max over ranks) run `runs` times; value "
-                                "and ms_per_step are the MEDIAN region; before them the same region runs unrecorded (twice "
-                                "when K < 200) so that none of the recorded ones sees the clock ramp",
+                                "and ms_per_step are the MEDIAN region; before them the same region runs unrecorded (when "
+                                "K < 200: twelve times) so that none of the recorded ones "
+                                "sees the ramp after the device's idle phases",
                         "gpu": sampler.summary()},
             "mode": "APPROX (--approx, development A/B only)" if a.approx else
                     "exact (library default): inlier counts and winners equal the reference kernels'",
