@@ -730,8 +730,9 @@ def main(argv=None):
                                    "constant-rate clock, averaged over the launches (pvnet_vote_v3_stage_repeat): the "
                                    "duration a kernel trace reports; the event figure adds the dependent-launch boundary",
                          "variant": "two accumulator pairs (a batch alone); the multi-stream regions of `value` run the "
-                                    "one-pair variant selected by PVNET_F_CONCURRENT, ~2 % slower per launch "
-                                    "(profiles/r03_ab_small_stage_shapes.txt)",
+                                    "variant selected by PVNET_F_CONCURRENT: one accumulator pair + contiguous item runs (B columns, "
+                                    "hypotheses and counters kept per run), slower alone, +2.5 % with batches in flight "
+                                    "(profiles/r04_ab_runs.txt)",
                          "pair_tests_per_s": pairs / score_s,
                          "vs_fp32_vector_peak": alg_tflops / PEAK_F32_TFLOPS,
                          "executed_flop_per_pair": MFMA_FLOP_PER_PAIR, "executed_tflops": exec_tflops,
@@ -740,7 +741,7 @@ def main(argv=None):
                          "mfma_busy_frac": busy, "mfma_busy_frac_from_committed_profile": busy_tag,
                          "note": "frac prices the 12 algorithmic fp32 flop of a pair test (SURVEY 8d); the kernel EXECUTES "
                                  "64 matrix flop per test (bf16x3 split: two v_mfma_f32_32x32x16_bf16 per 32x32 tests, K = "
-                                 "15 of 16 slots) = executed_frac, and 2.5 VALU operations per test for the vote and the "
+                                 "15 of 16 slots) = executed_frac, and 2.5 VALU operations per test (1 of them in the fast issue class since round 4) for the vote and the "
                                  "rounding band, which is what binds it (DESIGN.md section 5)"},
             "roofline_hbm": {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "compulsory_bytes": compulsory, "compulsory_gbs": compulsory / step_s / 1e9,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PVNET_VOTE_ABI_VERSION 6
+#define PVNET_VOTE_ABI_VERSION 7
 
 /* negative library error codes */
 #define PVNET_E_BADARG      (-1)   /* null pointer / non-positive size / unsupported dtype or stride */
@@ -47,14 +47,17 @@ extern "C" {
 #define PVNET_F_LITERAL   1u       /* score with the reference's float32 operation order (sqrt + divide, one
                                       rounding per op) on the VALU for EVERY (pixel, hypothesis) pair: bit-exact with
                                       oracle32 and with the reference's own kernels, ~10x slower.
-                                      DEFAULT (neither this flag nor PVNET_F_APPROX; "exact mode", ABI 6): the same
-                                      integers -- inlier counts and winners EQUAL the reference kernels' -- at matrix-
-                                      pipe speed: every pair is tested as |d x u| < tan(acos(thresh)) * (d . u) by two
-                                      bf16x3 MFMAs, the margin leaves the MFMA epilogue through a saturating ramp whose
-                                      width is the provable float32 rounding band of ransac_voting_kernel.cu:107-125
-                                      plus the matrix pipe's own error, and only the cells that hold a pair INSIDE the
-                                      band (~1e-5 of the pairs at thresh 0.99) are re-evaluated in the reference's
-                                      operation order (pvnet_vote.hip: score_exact_kernel) */
+                                      DEFAULT (neither this flag nor PVNET_F_APPROX; "exact mode", ABI 6+): the same
+                                      integers -- inlier counts and winners EQUAL the reference kernels' (the reading of
+                                      ransac_voting_kernel.cu with one rounding per operation, -ffp-contract=off; nvcc's
+                                      --fmad=true moves ~1e-6 of the reference's own flags) -- at matrix-pipe speed: every
+                                      pair is tested as |d x u| < tan(acos(thresh)) * (d . u) by two bf16x3 MFMAs in units of
+                                      the provable float32 rounding band of ransac_voting_kernel.cu:107-125 plus the matrix
+                                      pipe's own error, and only the cells that hold a pair INSIDE the band (~6e-5 of the
+                                      pairs at thresh 0.99) are re-evaluated in the reference's operation order
+                                      (pvnet_vote.hip: score_exact_body; the band's measured safety
+                                      margin: pvnet_vote_band_margin below).  Without the matrix-pipe buffers
+                                      (PVNET_SCORE_MODE=0) the default is scored literally (ABI 7) */
 #define PVNET_F_NO_REFINE 2u       /* skip ransac_voting_gpu.py:579-595, return the winning hypotheses */
 /* element type of `vertex` (and, for pvnet_vote_v3_logits, of `seg_pred`) when it is not float32 -- what a backbone under
  * autocast emits.  The pointer is passed through the `const float*` parameter and read as the flagged type; strides stay
@@ -74,9 +77,12 @@ extern "C" {
                                       spare words ctrl[b][4], ctrl[b][5] of the workspace (tools/exact_probe.py) */
 #define PVNET_F_CONCURRENT 256u    /* hint (results do not depend on it): the caller keeps OTHER batches in flight on other streams.
                                       The exact-mode scoring kernel then runs with one accumulator pair (136 instead of 168
-                                      VGPRs, ~2 % slower alone), which leaves room on every SIMD for the small stages of the
-                                      other batches: +3 % throughput with six batches in flight, -1.5 % for a batch alone.
-                                      The Python front end sets it by itself when consecutive calls alternate streams. */
+                                      VGPRs), which leaves room on every SIMD for the small stages of the other batches, and
+                                      (ABI 7) every workgroup takes a contiguous run of work items, keeping its B columns,
+                                      hypotheses and vote counters while the (image, key-point) stays the same: +4 %
+                                      throughput with six batches in flight, -5 % for a batch alone (profiles/r04_ab_runs.txt).
+                                      The Python front end sets it when consecutive calls alternate streams
+                                      (voting.concurrent_hint; concurrent=True / False decide explicitly). */
 
 /* per-(image,key-point) status bits written to out_status */
 #define PVNET_S_SKIPPED   1        /* fewer than min_num foreground pixels (or none kept): zeros returned */

@@ -22,11 +22,11 @@
 //                     zeroes its inlier count; one extra block per image plans the scoring work items
 //   K4 score          DOMINANT.  The vote is two 3-term fp32 dot products and a compare; every operand is split into
 //                     three bf16 parts, so each dot product is ONE v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
-//                     EXACT mode (default, score_exact_kernel): the two MFMAs return a = dt - cr and b = dt + cr in units of
-//                     the float32 rounding band of the reference's test; the lane that owns the hypothesis takes
-//                     x = min(a, b, 1) (exactly 1.0f for a vote, <= -1 for a non-vote outside the band), keeps min |x|
-//                     and counts the votes from packed-norm halves: 2 MFMAs + 2.25 VALU ops per test (vote8x); cells
-//                     that hold a test inside the band are re-evaluated with the reference's own arithmetic
+//                     EXACT mode (default, score_exact_body): the two MFMAs return dt and cr in units of the float32 rounding
+//                     band of the reference's test; the lane that owns the hypothesis takes x = dt - |cr| (>= 1 for a vote
+//                     outside the band, <= -1 for a non-vote outside it), keeps min |x| and counts the votes from packed-norm
+//                     halves: 2 MFMAs + 2.5 VALU ops per test, ordered for the SIMD's two issue ports (vote_subs / vote_slow_*);
+//                     cells that hold a test inside the band are re-evaluated with the reference's own arithmetic
 //                     (inlier_literal) from the raw records, so every inlier count EQUALS the reference kernel's.
 //                     APPROX mode (PVNET_F_APPROX, score_mfma_kernel): t = clamp(dt - |cr|) on 2^60-scaled records,
 //                     2 MFMAs + 1.5 VALU ops per test (vote8), no re-evaluation: counts within a few votes.
@@ -293,19 +293,17 @@ __device__ __forceinline__ void b_col(float x, float y, uint4& lo, uint4& hi) {
 //     B column scaled by  s_j     = 0.9 / ((R_j + rho) kband)         (rounded DOWN to a bf16, so s * c parts stay exact)
 //     A row    scaled by  sigma_i = (rho / (rho + r_i)) / |u_i|       (any float: the direction is normalised as well)
 // give  |s_j sigma_i m| < 1  for every pair inside the band -- also as the matrix pipe computes it.  The two MFMAs return
-//     a' = s sigma (dt - cr),   b' = s sigma (dt + cr)        (dt - |cr| = min(a, b): the |.| is gone from the epilogue)
-// so that  x = min(a', b', 1)  [one v_min3_f32] is EXACTLY 1.0f for a vote outside the band, <= -1 for a non-vote outside
-// the band and strictly between for a test inside it.  Cells with min |x| >= 1 hold only tests on which the reference's
-// arithmetic and exact arithmetic agree, and their votes are counted from the x's (vote8x); a cell with min |x| < 1 is
-// re-evaluated with inlier_literal() from the raw records and its x's are discarded.
-// = 2.25 VALU operations per test (1.5 in the approximate mode).  Measured alternatives (tools/ubench_exact.hip,
-// profiles/r03_ubench_exact.txt): t = clamp(min(a', b')) + min3(|a'|, |b'|) + add3 on float patterns, 2.5 operations:
-// 12.8 T tests/s against this form's 13.8 T; a float16 ramp (v_fma_mixlo/hi_f16) with byte moments (v_perm_b32 +
-// v_dot4_u32_u8), 1.75 operations on paper: 11.5 T -- VOP3P instructions issue at about half rate on gfx950.
+//     dt' = s sigma dt,   cr' = s sigma cr        (round 3: a' = dt' - cr' and b' = dt' + cr', merged by a three-input minimum)
+// so that  x = dt' - |cr'|  [one v_sub_f32 with a source modifier: the fast issue class, tools/ubench_issue.py] is >= 1 for a
+// vote outside the band, <= -1 for a non-vote outside the band and strictly between for a test inside it.  Cells with
+// min |x| >= 1 hold only tests on which the reference's arithmetic and exact arithmetic agree, and their votes are counted
+// from the x's (saturating pknorm); a cell with min |x| < 1 is re-evaluated with inlier_literal() from the raw records and its
+// x's are discarded.  = 2.5 VALU operations per test (1.5 in the approximate mode).  Alternatives measured in rounds 3 and 4:
+// DESIGN.md section 4 (tools/ubench_exact.hip, tools/ubench_issue.py).
 // Range gates: |h - o| >= 2^61 (or not finite) and |u| >= 2^61 would overflow the reference's squares -- such columns /
-// rows are sent as zeros: a' = b' = 0 flags every cell they touch, which is then decided by the reference's arithmetic
+// rows are sent as zeros: x = 0 flags every cell they touch, which is then decided by the reference's arithmetic
 // itself, whatever that does.  Zero records (padding, |u| < 1e-6) and NaN / Inf directions never vote in the reference;
-// their rows are zero except for the spare 16th K slot, A[15] = -4 against B[15] = 1: a' = b' = -4, no vote, no flag.
+// their dt' rows are zero except for the spare 16th K slot, A[15] = -4 against B[15] = 1: x = -4, no vote, no flag.
 // (Exact mode compacts like literal mode: records keep the RAW direction even below the gate, because the reference's
 // hypothesis generation reads it -- a 1e-7 direction paired with a 1e12 one has a determinant far above ITS gate.)
 constexpr float BAND_TARGET = 0.9f;             // |s sigma m| inside the band (proof obligation: < 1 with the float roundings of the scales)
@@ -328,7 +326,7 @@ __device__ __forceinline__ void b_col_exact(float hxo, float hyo, float rho, flo
     float s = BAND_TARGET / ((R + rho) * kband);
     s = __uint_as_float(__float_as_uint(s) & 0xFFFF0000u);  // round down to bf16: s * (c0 + c1 + c2) stays exact
     const uint32_t one = 0x3F80u;
-    if (!(R < BAND_FAR) || !(s > 0.f)) {  // too far, Inf or NaN: a' = b' = 0 for every live pixel -> decided literally
+    if (!(R < BAND_FAR) || !(s > 0.f)) {  // too far, Inf or NaN: x = 0 for every live pixel -> decided literally
         lo = make_uint4(0u, 0u, 0u, 0u);
         hi = make_uint4(0u, 0u, 0u, pk(0u, one));
         return;
@@ -339,10 +337,10 @@ __device__ __forceinline__ void b_col_exact(float hxo, float hyo, float rho, flo
     lo = make_uint4(q0, q0, q1, q0);
     hi = make_uint4(q2, q1, pk(sb, sb), pk(sb, one));
 }
-// per-pixel rows of a = dt - cr and b = dt + cr, the direction normalised to |M| = sigma <= rho / (rho + r)
+// per-pixel rows of dt' and cr', the direction normalised to |M| = sigma <= rho / (rho + r)
 __device__ __forceinline__ void a_rows_exact(float4 q, float tau, float ox, float oy, float rho, uint4& alo, uint4& ahi,
                                              uint4& blo, uint4& bhi) {
-    const uint32_t never = 0xC080u;  // bf16 -4 in the spare slot: a' = b' = -4
+    const uint32_t never = 0xC080u;  // bf16 -4 in the spare slot of the dt' row: x = -4
     alo = ahi = blo = bhi = make_uint4(0u, 0u, 0u, 0u);
     const float m = fmaxf(fabsf(q.z), fabsf(q.w));
     const uint32_t e = (__float_as_uint(m) >> 23) & 0xFFu;
@@ -1193,14 +1191,13 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
 // K4 (exact mode, the default): the matrix-pipe scoring of score_mfma_kernel with the rounding-band epilogue
 // described above b_col_exact(): counts EQUAL to the reference kernel's, 2.5 VALU operations per test.
 // ------------------------------------------------------------------------------------------------------------
-// Eight tests of the lane's hypothesis in 18 VALU operations (2.25 per test):
-//   x = min(a', b', 1)            v_min3_f32: exactly 1.0f = a vote outside the band, <= -1 = a non-vote outside the band,
-//                                 anything in between = a test inside the band (dt' - |cr'| = min(a', b'))
+// Eight tests of the lane's hypothesis in 18 VALU operations (2.25 per test; cells of a whole work item, FOLD = 0):
+//   x = d - |c|                   v_sub_f32 with a source modifier (d = dt', c = cr' of the two MFMAs): >= 1 = a vote outside the
+//                                 band, <= -1 = a non-vote outside the band, anything in between = a test inside the band
 //   dm = min(dm, |x|, |x'|)       v_min3_f32, two tests per instruction: the cell is clean iff dm >= 1
 //   w = pknorm_u16(x, x')         v_cvt_pknorm_u16_f32, two tests per instruction: clamp(x) * 65535 -> 0xFFFF for a vote, 0 else
 //   acc += w + w'                 v_add3_u32, four tests per instruction (wraps; votes_of_norm() decodes)
-// Measured beside the MFMAs (tools/ubench_exact.hip, profiles/r03_ubench_exact.txt): 13.8 T tests/s against 12.8 T for
-// "v_min clamp + v_min3 |a|, |b| + v_add3 on float patterns" (2.5 operations) and 16.7-18 T for the approximate mode's 1.5.
+// (parameter names a_i / b_i: the dt' / cr' values -- round 3 passed a' = dt' - cr', b' = dt' + cr' and took min3(a', b', 1))
 __device__ __forceinline__ void vote8x(unsigned& acc, float& dm, float a0, float b0, float a1, float b1, float a2, float b2,
                                        float a3, float b3, float a4, float b4, float a5, float b5, float a6, float b6,
                                        float a7, float b7) {

@@ -101,7 +101,7 @@ def load_library() -> C.CDLL:
     lib.pvnet_vote_band_margin.argtypes = [C.c_float, C.c_void_p] + ws_tail
     lib.pvnet_vote_tuning_reload.restype = None
     lib.pvnet_vote_tuning_reload.argtypes = []
-    if lib.pvnet_vote_abi_version() != 6:
+    if lib.pvnet_vote_abi_version() != 7:
         raise RuntimeError("pvnet_amd: libpvnet_vote.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib
