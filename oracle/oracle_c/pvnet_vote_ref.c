@@ -191,6 +191,28 @@ static __thread size_t tl_cap[5];
  * vertex element (bi,y,x,k,c) at vertex[bi*vs[0]+y*vs[1]+x*vs[2]+k*vs[3]+c*vs[4]] (strides in elements);
  * idxs: NULL (counter RNG) or [b,hn,vn,2]; out [b,vn,2]; win_idx/win_cnt [b,vn] optional.
  * Refinement accumulates in float64 (the "oracle32 + f64 LSQ" flavour of the numpy oracle). Returns 0. */
+/* thinning table (oracle/ransac_voting_oracle.py: thin_bin / subsample_threshold; pvnet_amd/csrc/pvnet_rng.h): 1/1024 steps of the
+ * probability down to 1/64, sixteen bins per octave of the random word below */
+static int thin_bin(uint32_t r) {
+    if (r >> 26) return 400 + (int)(r >> 22);
+    if (r == 0u) return 0;
+    int e = 25;
+    while (!((r >> e) & 1u)) --e;
+    uint32_t sub = e >= 4 ? (r >> (e - 4)) & 15u : (r << (4 - e)) & 15u;
+    return e * 16 + (int)sub;
+}
+static uint64_t thin_threshold(long long max_num, long long tn0) {   /* keep <=> word < threshold */
+    unsigned long long t = (unsigned long long)((((unsigned __int128)max_num) << 32) + (unsigned long long)tn0 - 1) / (unsigned long long)tn0;
+    int k = t == 0ull ? 0 : thin_bin((uint32_t)(t - 1ull)) + 1;
+    if (k > 400 + 1023) return 1ull << 32;
+    uint64_t lo = 0, hi = 1ull << 32;                                /* the first word whose bin is >= k */
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) / 2;
+        if (thin_bin((uint32_t)mid) >= k) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
 /* image_base: global index of image 0 of this call -- the RNG stream of image bi is image_base + bi, as the product's
  * `image_base` argument (include/pvnet_vote.h): lets a checker vote the images of a batch one by one. */
 int ref_vote_v3_base(const uint8_t* fg, const float* vertex, const int64_t* vs, int b, int h, int w, int vn, int hn,
@@ -205,8 +227,8 @@ int ref_vote_v3_base(const uint8_t* fg, const float* vertex, const int64_t* vs, 
         for (int p = 0; p < h * w; ++p) tn0 += m[p] != 0;                          /* :527-528 */
         if (tn0 < min_num) continue;                                                /* :531-534 */
         uint64_t thr = 1ull << 32;
-        if (tn0 > max_num)                                                          /* :537-540, probability rounded */
-            thr = (uint64_t)((1024ll * max_num + tn0 - 1) / tn0) << 22;             /* up to k / 1024 (oracle .py) */
+        if (tn0 > max_num)                                                          /* :537-540, probability rounded up to */
+            thr = thin_threshold(max_num, tn0);                                     /* the next bin edge (oracle .py)      */
         float* coords = (float*)scratch(&tl_buf[0], &tl_cap[0], sizeof(float) * 2 * (size_t)tn0);
         float* direct = (float*)scratch(&tl_buf[1], &tl_cap[1], sizeof(float) * 2 * (size_t)vn * tn0);
         int tn = 0;

@@ -86,17 +86,45 @@ def draw_idxs(seed: int, image: int, hn: int, vn: int, tn: int) -> np.ndarray:
     return ((r * np.uint64(tn)) >> np.uint64(32)).astype(np.int32).reshape(hn, vn, 2)
 
 
+THIN_LOG_BINS = 416            # 26 octaves (leading one at bit 0 .. 25) x 16 bins
+THIN_LAST = THIN_LOG_BINS - 16 + 1023
+
+
+def thin_bin(r: int) -> int:
+    """bin of a 32-bit random word (pvnet_amd/csrc/pvnet_rng.h: pvnet_thin_bin): steps of 1/1024 of the probability down to
+    1/64 (r >> 22 = 16 .. 1023 -> bins 416 .. 1423), sixteen bins per octave of r below; monotone in r."""
+    r = int(r)
+    if r >> 26:
+        return THIN_LOG_BINS - 16 + (r >> 22)
+    if r == 0:
+        return 0
+    e = r.bit_length() - 1
+    sub = (r >> (e - 4)) & 15 if e >= 4 else (r << (4 - e)) & 15
+    return e * 16 + sub
+
+
 def subsample_threshold(max_num: int, tn0: int) -> int:
     """keep  <=>  rng_u32 < threshold.  ransac_voting_gpu.py:537-540 keeps a pixel with probability max_num / tn0 when
-    tn0 > max_num; here the probability is rounded UP to the next multiple of 1/1024 -- k = ceil(1024 max_num / tn0),
-    threshold = k << 22, i.e. keep <=> (rng >> 22) < k -- so that the mask kernel can count, per 4096-pixel segment, how
-    many pixels every one of the 1024 possible decisions keeps (a cumulative histogram of the top ten bits) before tn0 is
-    known, and compaction needs no separate thinning launch.  Expected kept pixels: tn0 k / 1024 in [max_num,
-    max_num + tn0 / 1024)."""
+    tn0 > max_num; here the probability is rounded UP to the next edge of a bin table (thin_bin) -- K = thin_bin(T - 1) + 1
+    bins are kept, T = ceil(2^32 max_num / tn0), and the threshold is the first word of bin K -- so that the mask kernel can
+    count, per 4096-pixel segment, how many pixels every one of the 1424 possible decisions keeps (a cumulative histogram of
+    the bins) before tn0 is known, and compaction needs no separate thinning launch.  Round 4: the table has 1/1024 steps of
+    the probability down to 1/64 and relative steps of <= 1/16 below (rounds 2-3: 1/1024 steps only, +17 .. +58 % pixels at
+    max_num = 100).  Expected kept pixels: in [max_num, min(max_num + tn0 / 1024, max_num 17 / 16)]."""
     if tn0 <= max_num:
         return 1 << 32
-    k = (1024 * int(max_num) + int(tn0) - 1) // int(tn0)
-    return k << 22
+    t = ((int(max_num) << 32) + int(tn0) - 1) // int(tn0)
+    k = 0 if t == 0 else thin_bin(t - 1) + 1
+    if k > THIN_LAST:
+        return 1 << 32
+    lo, hi = 0, 1 << 32            # the first word whose bin is >= k (thin_bin is monotone)
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if thin_bin(mid) >= k:
+            hi = mid
+        else:
+            lo = mid + 1
+    return lo
 
 
 def subsample_keep(seed: int, image: int, npix: int, max_num: int, tn0: int) -> np.ndarray:

@@ -94,8 +94,9 @@ constexpr int K1_WAVES = PVNET_K1_WAVES;  // waves per K1 workgroup (one workgro
                                           // batch (PVNET_F_CONCURRENT): +3 % with six batches in flight for -0.5 % alone
 constexpr int K1_WORDS_PER_WAVE = SEG_WORDS / K1_WAVES;  // independent loads in flight per lane
 constexpr int K2_WORDS_PER_BLOCK = SEG_WORDS;
-constexpr int THIN_BITS = 10;          // thinning probability = k / 2^THIN_BITS (oracle: subsample_threshold)
-constexpr int THIN_BINS = 1 << THIN_BITS;
+// thinning: keep a pixel <=> pvnet_thin_bin(random word) < K (pvnet_rng.h; oracle: subsample_threshold): 1/1024 steps of the
+// probability down to 1/64, sixteen steps per octave below (round 4; rounds 2-3: the top ten bits only)
+constexpr int THIN_BINS = (PVNET_THIN_LAST + 1 + 127) / 128 * 128;   // 1536: histogram length, an EVEN number of bins per lane
 constexpr int PAD = 8;                 // scoring consumes records 8 at a time; tails are padded with sentinels
 
 struct VoteParams {
@@ -483,8 +484,8 @@ __global__ __launch_bounds__(64 * K1_WAVES) void mask_bits_kernel(VoteParams P) 
     for (int i = 0; i < K1_WAVES; ++i) t += s_cnt[i];
     if (threadIdx.x == 0) P.seg0[bi * P.nseg + blockIdx.x] = t;  // foreground pixels of this 4096-pixel segment (tn0 = their sum)
 
-    // Thinning (ransac_voting_gpu.py:537-540) keeps a pixel when the top THIN_BITS bits of its random word are below
-    // k = ceil(2^THIN_BITS max_num / tn0) -- but tn0 is only known when every segment has been counted.  So a segment
+    // Thinning (ransac_voting_gpu.py:537-540) keeps a pixel when the bin of its random word (pvnet_thin_bin) is below
+    // K = pvnet_thin_bins_kept(max_num, tn0) -- but tn0 is only known when every segment has been counted.  So a segment
     // WITH foreground (one in ten) also counts how many of its pixels EVERY possible k would keep (a cumulative histogram
     // of those bits, 2 KB), and the compaction kernel, which sums the segment counts anyway, picks its column: no separate
     // thinning launch.  Only when thinning can happen at all (max_num < h*w: P.cum is set).
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(64 * K1_WAVES) void mask_bits_kernel(VoteParams P) 
     const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_SUB, (uint32_t)(P.image_base + bi));
 #pragma unroll
     for (int i = 0; i < K1_WORDS_PER_WAVE; ++i)
-        if (f[i]) atomicAdd(&s_hist[pvnet_rng_at(key, (uint32_t)((word0 + i) * 64 + lane)) >> (32 - THIN_BITS)], 1);
+        if (f[i]) atomicAdd(&s_hist[pvnet_thin_bin(pvnet_rng_at(key, (uint32_t)((word0 + i) * 64 + lane)))], 1);
     __syncthreads();
     if (wave == 0) {  // inclusive prefix over the bins: cum[k - 1] = pixels of this segment kept at threshold k
         constexpr int PER = THIN_BINS / 64;  // consecutive bins per lane
@@ -573,10 +574,10 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
     int base = s_red[0] + s_red[1] + s_red[2] + s_red[3];
     if (tn0 > P.max_num) {
         // Thinning (block-uniform, rare: objects larger than max_num pixels, or the evaluation call site's max_num = 100):
-        // keep a pixel when the top THIN_BITS bits of its random word are below k (oracle: subsample_threshold).  The pixels kept in
+        // keep a pixel when the bin of its random word is below k (oracle: subsample_threshold).  The pixels kept in
         // earlier segments are column k - 1 of their cumulative histograms (K1); this segment's words are filtered here,
         // 16 bits per thread.
-        const int k = (int)(((long long)THIN_BINS * P.max_num + tn0 - 1) / tn0);  // 0 .. THIN_BINS
+        const int k = pvnet_thin_bins_kept(P.max_num, tn0);  // 0 .. PVNET_THIN_LAST + 1
         int part2 = 0;
         if (k > 0)
             for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256)
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
         while (todo) {
             const int bpos = __ffs((int)todo) - 1;
             todo &= todo - 1;
-            if ((int)(pvnet_rng_at(key, p0 + (uint32_t)bpos) >> (32 - THIN_BITS)) < k) kept |= 1u << bpos;
+            if (pvnet_thin_bin(pvnet_rng_at(key, p0 + (uint32_t)bpos)) < k) kept |= 1u << bpos;
         }
         __syncthreads();  // every read of s_word / s_red above has been performed
         s_piece[threadIdx.x] = (uint16_t)kept;
@@ -2496,8 +2497,9 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     if ((long long)hn * vn > (1ll << 24)) return PVNET_E_UNSUPPORTED;  // grid sizes and 32-bit indices
     const long long npix = (long long)h * w;
     long long cap = npix;
-    if (max_num < npix) {  // tn ~ Binomial(tn0, k / 1024), k = ceil(1024 max_num / tn0): mean < max_num + tn0 / 1024; 8 sigma
-        const long long mean = (long long)max_num + (npix + THIN_BINS - 1) / THIN_BINS;
+    if (max_num < npix) {  // tn ~ Binomial(tn0, p'), p' = max_num / tn0 rounded up to the next bin edge (pvnet_thin_bin): mean <
+                           // max_num + tn0 / 1024 where the steps are 1/1024, < max_num 17/16 below (there max_num / 16 < tn0 / 1024); 8 sigma
+        const long long mean = (long long)max_num + (npix + 1023) / 1024;
         const long long c = mean + 8ll * (long long)ceil(sqrt((double)mean)) + 64;
         cap = c < npix ? c : npix;
     }
