@@ -729,9 +729,10 @@ def main(argv=None):
                          "timing": "avg_launch_ms = max end - min start of the kernel's workgroups on the device's "
                                    "constant-rate clock, averaged over the launches (pvnet_vote_v3_stage_repeat): the "
                                    "duration a kernel trace reports; the event figure adds the dependent-launch boundary",
-                         "variant": "two accumulator pairs (a batch alone); the multi-stream regions of `value` run the "
-                                    "variant selected by PVNET_F_CONCURRENT: one accumulator pair + contiguous item runs (B columns, "
-                                    "hypotheses and counters kept per run), slower alone, +2.5 % with batches in flight "
+                         "variant": "a batch alone: strided work items, one accumulator pair in 128 VGPRs (four waves per SIMD), 12 "
+                                    "workgroups per CU; the multi-stream regions of `value` run the variant selected by "
+                                    "PVNET_F_CONCURRENT: contiguous item runs (B columns, hypotheses and counters kept per run) "
+                                    "in 136 VGPRs (three waves per SIMD), slower alone, +2.5 % with batches in flight "
                                     "(profiles/r04_ab_runs.txt)",
                          "pair_tests_per_s": pairs / score_s,
                          "vs_fp32_vector_peak": alg_tflops / PEAK_F32_TFLOPS,

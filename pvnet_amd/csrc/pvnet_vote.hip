@@ -1321,7 +1321,8 @@ constexpr float BAND_CLEAN = 1.0f;     // a cell whose minimum |a'|, |b'| reache
 template <int MH, int FOLD, bool TIMED, int NACC, bool RUNS_>
 __device__ __forceinline__ void score_exact_body(VoteParams P) {
     if (MH == 8 && NACC == 2) PVNET_SPARE_VGPRS(167);
-    else if (MH == 8) PVNET_SPARE_VGPRS(135);
+    else if (MH == 8 && RUNS_) PVNET_SPARE_VGPRS(135);
+    else if (MH == 8) PVNET_SPARE_VGPRS(127);  // (one pair, strided items: what a batch ALONE runs, four waves per SIMD)
     else if (MH == 4) PVNET_SPARE_VGPRS(143);
     else PVNET_SPARE_VGPRS(111);
     unsigned long long* __restrict__ stamps = reinterpret_cast<unsigned long long*>(P.pix);
@@ -1611,7 +1612,7 @@ template <int MH, int FOLD, bool TIMED, int NACC, bool RUNS> struct ScoreExact;
     PV_DEF_SCORE_EXACT(MH_, 0, 0, NACC_, RUNS_, NVGPR_) PV_DEF_SCORE_EXACT(MH_, 0, 1, NACC_, RUNS_, NVGPR_)              \
     PV_DEF_SCORE_EXACT(MH_, 1, 0, NACC_, RUNS_, NVGPR_) PV_DEF_SCORE_EXACT(MH_, 1, 1, NACC_, RUNS_, NVGPR_)
 PV_DEF_SCORE_EXACT4(1, 2, 0, 104) PV_DEF_SCORE_EXACT4(2, 2, 0, 104) PV_DEF_SCORE_EXACT4(4, 2, 0, 136)
-PV_DEF_SCORE_EXACT4(8, 1, 0, 128) PV_DEF_SCORE_EXACT4(8, 2, 0, 160)
+PV_DEF_SCORE_EXACT4(8, 1, 0, 120) PV_DEF_SCORE_EXACT4(8, 2, 0, 160)
 PV_DEF_SCORE_EXACT4(8, 1, 1, 128) PV_DEF_SCORE_EXACT4(8, 2, 1, 160)
 #undef PV_DEF_SCORE_EXACT4
 #undef PV_DEF_SCORE_EXACT
@@ -2204,7 +2205,8 @@ int env_int(const char* name, int dflt) {
 // -1 means "not set: use the shape-dependent default".
 struct Tuning {
     int score_mode;     // PVNET_SCORE_MODE        1: matrix-pipe scoring in fast mode, 0: the 6-op VALU kernel
-    int wgs_per_cu;     // PVNET_SCORE_WGS_PER_CU  scoring workgroups launched per CU (0: one per work item)
+    int wgs_per_cu;     // PVNET_SCORE_WGS_PER_CU  scoring workgroups launched per CU (0: one per work item; -1 (default): 8, and 12 for
+                        //                         an exact-mode batch alone at 8 tiles per wave -- four resident per CU, three rounds)
     int hpl;            // PVNET_SCORE_HPL         hypotheses per lane of the VALU kernel / MFMA tiles per wave
     int chunk;          // PVNET_SCORE_CHUNK       pixels per count row
     int compact_kg;     // PVNET_COMPACT_KG        key-points per compaction block
@@ -2216,7 +2218,8 @@ struct Tuning {
                         //                         0: per-chunk uint16 count rows (`partial`) summed by K5
     int score_acc;      // PVNET_SCORE_ACC         exact mode, 8 tiles per wave: accumulator pairs of the scoring loop (2: MFMAs of the
                         //                         next step issued around this step's votes; 1: one pair, 32 VGPRs fewer;
-                        //                         -1 (default): 1 for calls flagged PVNET_F_CONCURRENT, else 2)
+                        //                         -1 (default): 1 -- in 136 VGPRs for calls flagged PVNET_F_CONCURRENT (three waves per
+                        //                         SIMD), in 128 for a batch alone (four))
     int score_runs;     // PVNET_SCORE_RUNS        exact mode, 8 tiles per wave: 1 = contiguous item runs per workgroup (B columns, hypotheses and
                         //                         vote counters kept while the (image, key-point) stays), 0 = strided items;
                         //                         -1 (default): runs for calls flagged PVNET_F_CONCURRENT
@@ -2227,7 +2230,7 @@ struct Tuning {
 };
 void load_tuning(Tuning& t) {
     t.score_mode = env_int("PVNET_SCORE_MODE", 1);
-    t.wgs_per_cu = env_int("PVNET_SCORE_WGS_PER_CU", 8);
+    t.wgs_per_cu = env_int("PVNET_SCORE_WGS_PER_CU", -1);
     t.hpl = env_int("PVNET_SCORE_HPL", -1);
     t.chunk = env_int("PVNET_SCORE_CHUNK", -1);
     t.compact_kg = env_int("PVNET_COMPACT_KG", 3);
@@ -2334,7 +2337,9 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
     if (stages & 16) {   // K4: persistent grid, work items strided over its waves
         const long long max_items =
             (long long)P.b * P.vn * (P.hgroups / P.wg_g) * ((P.max_chunks + P.wg_s - 1) / P.wg_s);
-        const int wgs_per_cu = T.wgs_per_cu;
+        // (12: the four-waves-per-SIMD scoring kernel of a batch alone, three rounds of four resident workgroups; measured with it only)
+        const bool alone8 = P.exact && P.wg_g * P.hpl / 2 == 8 && !(P.flags & PVNET_F_CONCURRENT) && T.score_acc != 2 && T.score_runs != 1;
+        const int wgs_per_cu = T.wgs_per_cu >= 0 ? T.wgs_per_cu : (alone8 ? 12 : 8);
         long long wgs = wgs_per_cu > 0 ? (long long)T.cus * wgs_per_cu : max_items;  // 0: one workgroup per item
         if (wgs > max_items) wgs = max_items;
         if (wgs < 1) wgs = 1;
@@ -2347,11 +2352,13 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
             if (T.score_lds_kb > 0 && T.score_lds_kb <= 64 && lds < (size_t)T.score_lds_kb * 1024) lds = (size_t)T.score_lds_kb * 1024;
             const dim3 g((unsigned)wgs), t(256);
             const int fold = P.fold1;
-            // calls flagged PVNET_F_CONCURRENT (other batches in flight): contiguous runs + one accumulator pair; a batch alone:
-            // strided items + two pairs (PVNET_SCORE_ACC / PVNET_SCORE_RUNS force either; runs need cells of one pixel tile)
+            // calls flagged PVNET_F_CONCURRENT (other batches in flight): contiguous runs, one accumulator pair, three waves per
+            // SIMD (136 VGPRs; four cost 6 % there: profiles/r04_ab_runs.txt); a batch alone: strided items, one pair in 128
+            // VGPRs = four waves per SIMD (kernel -2 %), 12 workgroups per CU.  PVNET_SCORE_ACC=2 / PVNET_SCORE_RUNS force the
+            // round-3 form (two pairs, 168 VGPRs) / either mapping; runs need cells of one pixel tile.
             const bool conc = (P.flags & PVNET_F_CONCURRENT) != 0;
-            const bool one_acc = T.score_acc == 1 || (T.score_acc < 0 && conc);
-            const bool runs = fold == 1 && (T.score_runs == 1 || (T.score_runs < 0 && conc));
+            const bool one_acc = T.score_acc == 1 || T.score_acc < 0;
+            const bool runs = T.score_runs == 1 || (T.score_runs < 0 && conc);  // (cells of a whole item: the same 136-VGPR kernel, strided items)
 #define PV_EXACT3(MH_, NACC_, RUNS_)                                                                                \
     do {                                                                                                            \
         if (timed_score) {                                                                                          \
@@ -2648,7 +2655,8 @@ int pvnet_vote_v3_stage_repeat(const void* mask, int mask_dtype, const int64_t m
     // the matrix-pipe scoring kernel once more, `repeats` times, stamping the device clock itself (fast mode only)
     // ticks accumulate in the spare words of ctrl's global row; the stamps live in `pix` (consumed by K3 only; a later
     // complete call rewrites it), when the scoring grid's slots fit there
-    const long long score_wgs = tuning().wgs_per_cu > 0 ? (long long)tuning().cus * tuning().wgs_per_cu : (1ll << 40);
+    const int wgs_cu = tuning().wgs_per_cu >= 0 ? tuning().wgs_per_cu : 12;
+    const long long score_wgs = wgs_cu > 0 ? (long long)tuning().cus * wgs_cu : (1ll << 40);
     const bool device_clock = stage == PVNET_STAGE_SCORE && !(P.flags & PVNET_F_LITERAL) && P.mode &&
                               score_wgs * 48 <= (long long)sizeof(int32_t) * P.b * P.cap;
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(P.ctrl + P.b * CTRL_STRIDE + 2);
