@@ -76,10 +76,10 @@ extern "C" {
 #define PVNET_F_BAND_STATS 128u     /* development aid (exact mode): count the re-evaluated cells / literal tests into the two
                                       spare words ctrl[b][4], ctrl[b][5] of the workspace (tools/exact_probe.py) */
 #define PVNET_F_CONCURRENT 256u    /* hint (results do not depend on it): the caller keeps OTHER batches in flight on other streams.
-                                      The exact-mode scoring kernel then runs with one accumulator pair (136 instead of 168
-                                      VGPRs), which leaves room on every SIMD for the small stages of the other batches, and
-                                      (ABI 7) every workgroup takes a contiguous run of work items, keeping its B columns,
-                                      hypotheses and vote counters while the (image, key-point) stays the same: +4 %
+                                      The exact-mode scoring kernel then runs three waves per SIMD in 136 VGPRs (a batch alone:
+                                      four in 128, which would fill the SIMDs), leaving room for the small stages of the other
+                                      batches, and (ABI 7) every workgroup takes a contiguous run of work items, keeping its B
+                                      columns, hypotheses and vote counters while the (image, key-point) stays the same: +4 %
                                       throughput with six batches in flight, -5 % for a batch alone (profiles/r04_ab_runs.txt).
                                       The Python front end sets it when consecutive calls alternate streams
                                       (voting.concurrent_hint; concurrent=True / False decide explicitly). */

@@ -1311,8 +1311,10 @@ constexpr float BAND_CLEAN = 1.0f;     // a cell whose minimum |a'|, |b'| reache
 // NACC = 2: two accumulator pairs -- the MFMAs of step i + 1 are issued around the votes of step i (the flat pipeline of the
 //           approximate kernel);
 // NACC = 1: one pair -- a wave issues the step's two MFMAs and consumes their results right away, the SIMD's other waves
-//           fill the wait.  tools/ubench_exact.hip: 13.48 against 13.67 T tests/s at 3 waves per SIMD -- and 32 VGPRs fewer,
-//           which other streams' small stages can use while this kernel is resident (PVNET_SCORE_ACC).
+//           fill the wait.  tools/ubench_exact.hip: 13.48 against 13.67 T tests/s at 3 waves per SIMD -- and 32 VGPRs fewer:
+//           in 136 (RUNS) other streams' small stages can be resident beside this kernel, in 128 (strided items, a batch
+//           alone) a SIMD holds four of its waves, 2 % faster alone and 6 % slower with batches in flight (r04d1-r04d5 in
+//           profiles/r04_ab_runs.txt).  The default since the end of round 4; PVNET_SCORE_ACC=2 brings the two pairs back.
 // RUNS (round 4; cells of one pixel tile only): the workgroup's items are a CONTIGUOUS run of the list -- while the (image,
 //           key-point, hypothesis slice) stays the same, the B columns stay in registers, the hypotheses in LDS and the clean cells'
 //           votes in their counters: loaded / flushed once per run instead of once per 256-pixel item.  Same-box A/B
@@ -1595,7 +1597,7 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
     }
 #undef PV_PHASE
 }
-// The register allocator fills whatever budget the occupancy target leaves (3 waves per SIMD: 168 VGPRs), the library needs
+// The register allocator fills whatever budget the occupancy target leaves (3 waves per SIMD: up to 168 VGPRs), the library needs
 // the top granule of every allocation unused (PVNET_SPARE_VGPRS): amdgpu_num_vgpr -- a literal, hence one definition per
 // instantiation -- caps what the code may use one granule below what PVNET_SPARE_VGPRS makes the kernel allocate (the
 // backend doubles the attribute's value on targets with a unified VGPR / AGPR file, hence the / 2).

@@ -17,9 +17,9 @@ from pvnet_amd import synth, voting  # noqa: E402
 dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 START = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # first case (cases are seeded by their number)
-KNOBS = {"PVNET_SCORE_XCD": ["0", "1"], "PVNET_SCORE_ATOMIC": ["0", "1"], "PVNET_SCORE_WGS_PER_CU": ["0", "2", "8"],
-         "PVNET_COMPACT_KG": ["1", "3", "9"], "PVNET_EXACT_FOLD": ["0", "1"],
-         "PVNET_SCORE_ACC": ["1", "2"]}
+KNOBS = {"PVNET_SCORE_XCD": ["0", "1"], "PVNET_SCORE_ATOMIC": ["0", "1"], "PVNET_SCORE_WGS_PER_CU": ["-1", "0", "2", "8", "12"],
+         "PVNET_COMPACT_KG": ["1", "3", "9"], "PVNET_EXACT_FOLD": ["-1", "0", "1"],
+         "PVNET_SCORE_ACC": ["-1", "1", "2"], "PVNET_SCORE_RUNS": ["-1", "0", "1"]}
 bad_exact = 0
 bad = 0
 worst = {}
@@ -34,7 +34,7 @@ for case in range(START, N):
     b = int(rng.integers(1, 6))
     radius = int(rng.integers(3, max(4, min(h, w) // 2)))
     thresh = float(rng.choice([0.5, 0.9, 0.99, 0.999, 0.9999]))
-    max_num = int(rng.choice([30000, 1000, 150, 40]))
+    max_num = int(rng.choice([30000, 1000, 150, 40, 7]))
     mdt = rng.choice(["int64", "uint8", "int32"])
     scale = float(rng.choice([1.0, 1.0, 2.0 ** -3, 2.0 ** 9]))
     mask, planar, _ = synth.make_batch(b, first_index=9000 + 3 * case, h=h, w=w, vn=vn, radius=radius,
@@ -58,7 +58,8 @@ for case in range(START, N):
     live = nch > 0
     ok = np.array_equal(win_l[:, :, 0][live], wi[live]) and np.array_equal(win_l[:, :, 1][live], wc[live])
     hyp_l, out_l = dbg["hyp"].clone(), out.clone()
-    ex, de = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, max_num=max_num, seed=seed, return_debug=True)
+    ex, de = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, max_num=max_num, seed=seed, return_debug=True,
+                                           concurrent=bool(rng.integers(0, 2)))  # (the in-flight variant: contiguous item runs)
     same = (de["hyp"].cpu().numpy().tobytes() == hyp_l.cpu().numpy().tobytes() and torch.equal(de["counts"], counts_l)
             and np.array_equal(de["win"].cpu().numpy(), win_l))
     okpx = torch.isfinite(out_l).all(-1) & (out_l.abs() < 1e5).all(-1)
@@ -85,6 +86,8 @@ for case in range(START, N):
         print("MISMATCH case", case, dict(h=h, w=w, vn=vn, hn=hn, b=b, radius=radius, thresh=thresh, max_num=max_num, mdt=mdt,
                                           scale=scale), {k: os.environ[k] for k in KNOBS}, "winners_ok", ok,
               "max count diff fast-literal", cd, "finite", fin, flush=True)
+    if (case + 1) % 100 == 0:
+        print(f"... case {case + 1}: exact != literal {bad_exact}, other failures {bad}", flush=True)
 for k in KNOBS:
     os.environ.pop(k, None)
 voting.reload_tuning()
