@@ -258,3 +258,54 @@ def test_motion_voting():
     out = O.ransac_motion_voting(mask, vertex)
     np.testing.assert_allclose(out[0, 0], [(2 + 1 + 4 + 3) / 2, (1 + 2 + 3 - 2) / 2])
     np.testing.assert_allclose(out[0, 1], [3.0, 2.0])
+
+
+def test_thinning_table_header_and_oracles_agree(tmp_path):
+    """round 4: the keep rule of `max_num` (ransac_voting_gpu.py:537-540) is a table of 1 424 bins of the random word.  The header
+    the kernels include (pvnet_amd/csrc/pvnet_rng.h, compiled here for the host), the numpy oracle and -- through the thinned
+    pixel counts of vote_v3 -- the C oracle must state the same table; the table must be monotone, and the kept probability
+    must lie in [p, min(p + 1/1024, p 17/16)] for p = max_num / tn0."""
+    import ctypes
+    import subprocess
+    src = tmp_path / "thin.c"
+    src.write_text('#include "pvnet_rng.h"\n'
+                   "int t_bin(unsigned r) { return pvnet_thin_bin(r); }\n"
+                   "int t_kept(long long m, long long n) { return pvnet_thin_bins_kept(m, n); }\n"
+                   "int t_last(void) { return PVNET_THIN_LAST; }\n")
+    lib = tmp_path / "thin.so"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-I", os.path.join(root, "pvnet_amd", "csrc"), str(src), "-o", str(lib)])
+    L = ctypes.CDLL(str(lib))
+    L.t_kept.argtypes = [ctypes.c_longlong, ctypes.c_longlong]
+    assert L.t_last() == O.THIN_LAST == 1423
+    rng = np.random.default_rng(7)
+    words = np.concatenate([np.arange(0, 70), (1 << np.arange(0, 32)).astype(np.uint64), (1 << np.arange(1, 33)).astype(np.uint64) - 1,
+                            rng.integers(0, 1 << 32, 3000, dtype=np.uint64), rng.integers(0, 1 << 26, 3000, dtype=np.uint64),
+                            rng.integers(0, 1 << 12, 300, dtype=np.uint64)])
+    words = np.unique(words)
+    bins = [L.t_bin(int(r)) for r in words]
+    assert bins == [O.thin_bin(int(r)) for r in words]
+    assert all(a <= b for a, b in zip(bins, bins[1:])) and bins[0] == 0 and bins[-1] == O.THIN_LAST   # monotone, 0 .. 1423
+    for max_num, tn0 in [(100, 60000), (100, 101), (30000, 35000), (30000, 307200), (1, 307200), (0, 500), (7, 9000), (150, 151),
+                         (5, 1 << 31), (4999, 5000)] + [tuple(sorted(rng.integers(1, 400000, 2))) for _ in range(200)]:
+        max_num, tn0 = int(max_num), int(tn0)
+        if tn0 <= max_num:
+            continue
+        k = L.t_kept(max_num, tn0)
+        thr = O.subsample_threshold(max_num, tn0)
+        if k > O.THIN_LAST:
+            assert thr == 1 << 32                                        # every bin kept
+        else:                                                            # the threshold is the FIRST word of bin k
+            assert O.thin_bin(thr) >= k and (thr == 0 or O.thin_bin(thr - 1) < k)
+        p, kept = max_num / tn0, thr / 2.0 ** 32
+        assert p <= kept <= min(p + 1 / 1024, p * 17 / 16) + 1e-12, (max_num, tn0, p, kept)
+    # the C oracle thins with the same rule: same winners and counts as the numpy float32 restatement on thinned images
+    mask, planar, _ = synth.make_batch(2, first_index=77, h=120, w=160, radius=45, noise=True)
+    v = synth.planar_to_vertex_view(planar)
+    for max_num in (3000, 150, 7):
+        _, dbg = O.ransac_voting_layer_v3(mask, v, 32, inlier_thresh=0.99, max_num=max_num, seed=11, dtype=np.float32,
+                                          return_debug=True)
+        assert all(d["tn"] < d["tn0"] for d in dbg)
+        _, wi, wc = cref.vote_v3(mask != 0, v, 32, 0.99, max_num=max_num, seed=11, return_winners=True)
+        np.testing.assert_array_equal(wi, np.stack([d["win_idx"] for d in dbg]))
+        np.testing.assert_array_equal(wc, np.stack([d["win_cnt"] for d in dbg]))
