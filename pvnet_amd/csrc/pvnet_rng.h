@@ -48,8 +48,12 @@ PVNET_HD uint32_t pvnet_rng_below(uint32_t r, uint32_t n) { return (uint32_t)(((
 PVNET_HD int pvnet_thin_bin(uint32_t r) {
     if (r >> 26) return PVNET_THIN_LOG_BINS - 16 + (int)(r >> 22);     // linear part (r >> 22 = 16 .. 1023): 416 .. 1423
     if (r == 0u) return 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int e = 31 - __clz((int)r);                                    // position of the leading one, 0 .. 25: branch-free
+#else
     int e = 25;
-    while (!((r >> e) & 1u)) --e;                                        // position of the leading one, 0 .. 25
+    while (!((r >> e) & 1u)) --e;                                        // the same on the host (oracle builds compile this header with gcc)
+#endif
     const uint32_t sub = e >= 4 ? (r >> (e - 4)) & 15u : (r << (4 - e)) & 15u;
     return e * 16 + (int)sub;
 }

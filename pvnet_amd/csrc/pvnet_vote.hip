@@ -1394,8 +1394,10 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
         const int hslice = hq * 4 * MH * 32;            // first hypothesis of this work item
         const int h0 = hslice + wave * MH * 32;         // this wave's first hypothesis
         const long long key = (long long)bk * (P.hgroups / P.wg_g) + hq;
-        // workgroup-uniform: a new run (the counters hold < 65536 votes per half: a run is cut after 256 items)
-        const bool fresh = !RUNS || key != run_key || run_items >= 256;
+        // workgroup-uniform: a new run.  The packed-norm counters hold < 65536 votes per half: a lane adds 8 votes per half and
+        // pixel tile, half_wave_sum2 joins two lanes -- 16 * ntiles per item, so a run is cut after 65535 / (16 * ntiles) items
+        // (a fixed 256 overflowed from 16 tiles per item on, PVNET_SCORE_CHUNK >= 256)
+        const bool fresh = !RUNS || key != run_key || run_items >= 65535 / (16 * ntiles);
 
         lds_barrier();  // the previous item's tiles, raw records and cell list have been consumed
         PV_PHASE(3);

@@ -221,8 +221,8 @@ def reset_concurrent_hint(dev=None):
 
 def concurrent_hint(dev, concurrent: Optional[bool]) -> int:
     """PVNET_F_CONCURRENT or 0 for a call on the current stream of ``dev``.  The flag never changes a result; it picks the
-    variant of the scoring kernel that leaves registers to the small stages of OTHER batches in flight (+3 % throughput with
-    six batches on six streams, -1.5 % for a batch alone).  ``concurrent=None`` (the default of the callers): set when this
+    variant of the scoring kernel that leaves registers to the small stages of OTHER batches in flight (+4 % throughput with
+    six batches on six streams, -5 % for a batch alone: include/pvnet_vote.h, profiles/r04_ab_runs.txt).  ``concurrent=None`` (the default of the callers): set when this
     call's stream differs from the stream of the previous call on the device -- a caller that alternates streams keeps
     batches in flight; one that stays on a stream (the reference's call sites, DataParallel replicas: one stream per device)
     does not."""
@@ -515,14 +515,24 @@ def ransac_voting_layer_v5(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
     max_num = int(min(max(int(max_num), 0), 2 ** 31 - 1))
     out, dbg = ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh, confidence, max_iter, min_num,
                                       max_num, return_debug=True, **_strip_return_kw(kw))
+    return out, vote_confidence(dbg, out, conf_thresh)
+
+
+def vote_confidence(dbg, pts, conf_thresh=0.999):
+    """ransac_voting_layer_v5's second output for ANY points ``pts`` [b,vn,2] (ransac_voting_gpu.py:846-850): the fraction of the
+    kept pixels of a completed call (``dbg`` = its ``return_debug`` dict) whose direction points at ``pts`` within
+    ``conf_thresh``, in the reference's float32 operation order.  Enqueued on the current stream, like the call itself."""
     L, ws = dbg["layout"], dbg["workspace"]
-    conf = torch.empty((L.b, L.vn), dtype=torch.float32, device=out.device)
-    with torch.cuda.device(out.device):
-        _check(load_library().pvnet_vote_confidence(C.c_void_p(out.data_ptr()), C.c_float(conf_thresh),
+    pts = pts.to(device=ws.device, dtype=torch.float32).contiguous()
+    if tuple(pts.shape) != (L.b, L.vn, 2):
+        raise RuntimeError(f"pts must be [b,vn,2]={(L.b, L.vn, 2)}, got {tuple(pts.shape)}")
+    conf = torch.empty((L.b, L.vn), dtype=torch.float32, device=ws.device)
+    with torch.cuda.device(ws.device):
+        _check(load_library().pvnet_vote_confidence(C.c_void_p(pts.data_ptr()), C.c_float(conf_thresh),
                                                     C.c_void_p(conf.data_ptr()), F_LITERAL if dbg["literal"] else 0,
-                                                    *_ws_tail(L, max_num, ws)),
+                                                    *_ws_tail(L, int(dbg["max_num"]), ws)),
                "pvnet_vote_confidence")
-    return out, conf
+    return conf
 
 
 def estimate_voting_distribution_with_mean(mask, vertex, mean, round_hyp_num=256, min_hyp_num=4096, topk=128,

@@ -1,4 +1,4 @@
-"""world_size-2 gloo tests of the sharding / gather logic (pvnet_amd/distributed.py).  No GPU here, so the voter
+"""world_size-2 (and one world_size-8) gloo tests of the sharding / gather logic (pvnet_amd/distributed.py).  No GPU here, so the voter
 is injected: the numpy oracle plays the voter *as the checker's stand-in* -- this tests the N>1 plumbing
 (shard ownership, global RNG streams, the single all-gather, ragged tails), not the HIP kernels."""
 import os
@@ -67,6 +67,45 @@ def test_two_ranks_reproduce_the_unsharded_batch(total):
     for r in range(2):
         assert res[r].shape == (total, 9, 2)
         np.testing.assert_array_equal(res[r], ref)  # same global RNG streams, same order, on every rank
+
+
+def _worker_cfg3(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s, e = D.shard_range(total, world, rank)
+        # every rank builds ONLY its own block (global image indices s .. e - 1), as a data loader would hand it over
+        mask, planar, _ = synth.make_batch(e - s, first_index=4000 + s, h=48, w=64, radius=7, noise=True)
+        vertex = synth.planar_to_vertex_view(planar)
+        full = D.sharded_ransac_voting_layer_v3(torch.from_numpy(mask), torch.from_numpy(vertex.copy()), 16, 0.99,
+                                                total=total, voter=_oracle_voter, seed=77)
+        q.put((rank, full.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_split_baseline_config3_like_the_north_star():
+    """BASELINE configs[3]: batch 256 sharded over 8 ranks -- 32 images per rank, contiguous blocks, ONE all-gather of
+    [32, vn, 2] -- must return, on every rank, exactly what the unsharded call returns.  World size 8 on
+    gloo / CPU; the voter is the numpy oracle standing in for the HIP layer: this covers the N = 8 plumbing the driver's
+    `bench.py --gpus 8` run relies on (shard ownership, RNG streams by GLOBAL image index, the single collective)."""
+    world, total = 8, 256
+    assert [D.shard_range(total, world, r) for r in range(world)] == [(32 * r, 32 * r + 32) for r in range(world)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_cfg3, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    mask, planar, _ = synth.make_batch(total, first_index=4000, h=48, w=64, radius=7, noise=True)
+    ref = O.ransac_voting_layer_v3(mask, synth.planar_to_vertex_view(planar), 16, 0.99, seed=77)
+    assert ref.shape == (total, 9, 2)
+    for r in range(world):
+        np.testing.assert_array_equal(res[r], ref)   # every rank holds the unsharded result, byte for byte
 
 
 def _seed_echo_voter(mask, vertex, hn, *a, seed=0, image_offset=0, **kw):

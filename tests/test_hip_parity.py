@@ -13,6 +13,9 @@ from pvnet_amd import synth, voting
 pytestmark = pytest.mark.gpu
 
 TOL_PX = 1e-3  # north_star: key-points within 1e-3 px of the reference on identical inputs
+# votes per hypothesis by which FLOAT64 arithmetic (oracle64) may differ from the reference's float32 decisions on threshold-edge
+# pixels (SURVEY hard part 2).  It bounds the oracle's arithmetic, not a mode: the default mode's counts EQUAL literal mode's.
+F64_EDGE_VOTES = 2
 
 
 def dev():
@@ -111,13 +114,15 @@ def test_fast_mode_against_oracle64():
     cnt = dbg["counts"].cpu().numpy().transpose(0, 2, 1)
     ref = np.stack([d["counts"] for d in d64])
     diff = np.abs(cnt - ref)
-    assert diff.max() <= 2 and (diff > 0).mean() < 0.02  # only threshold-edge pixels may flip (SURVEY hard part 2)
+    # (float64 arithmetic against the reference's float32 decisions: only threshold-edge pixels may flip, SURVEY hard part 2 --
+    # this is the ORACLE's arithmetic differing from the reference's, not slack of the mode: against literal mode, below, none)
+    assert diff.max() <= F64_EDGE_VOTES and (diff > 0).mean() < 0.02
     win64 = np.stack([d["win_idx"] for d in d64])
     winf = dbg["win"][:, :, 0].cpu().numpy()
     flip = win64 != winf
     if flip.any():  # a tie-break between hypotheses that exact arithmetic counts within 2 votes of each other
         bi, ki = np.nonzero(flip)
-        assert np.abs(ref[bi, winf[bi, ki], ki] - ref[bi, win64[bi, ki], ki]).max() <= 2
+        assert np.abs(ref[bi, winf[bi, ki], ki] - ref[bi, win64[bi, ki], ki]).max() <= F64_EDGE_VOTES
         assert np.abs(out.cpu().numpy() - o64)[flip].max() < 5e-2
     assert np.abs(out.cpu().numpy() - o64)[~flip].max() < TOL_PX
     # (the slack above is float64 arithmetic against the reference's float32 decisions; against LITERAL mode -- the reference's
@@ -238,6 +243,12 @@ def test_thinning_without_its_own_launch_edge_cases(max_num_of):
     ok = np.isfinite(ref).all(-1) & (np.abs(ref) < 1e4).all(-1)
     ok &= dbg["status"].cpu().numpy() == 0   # (a pixel or two kept: no inlier / a singular normal matrix -- the reference raises there)
     ok &= (dbg["tn"][:3].cpu().numpy() >= 5)[:, None]   # (two or three noisy rays: a 2x2 system too ill-conditioned for 1e-3 px)
+    #  which parametrisations MUST reach the key-point comparison: with thousands (tn0 - 1, tn0 // 3) or ~100 kept
+    # pixels every live image refines; max_num = 1 / 0 keep one pixel or none (no inlier / singular: nothing to compare)
+    if max_num_of in ("tn0-1", "tn0//3"):
+        assert ok.all(), "every key-point of every image must be comparable here"
+    elif max_num_of == "97":
+        assert ok[:2].any()
     if ok.any():
         assert np.abs(out.cpu().numpy() - ref)[ok].max() < 1e-3
 
@@ -587,9 +598,10 @@ def test_randomised_shapes_literal_vs_c_oracle(case):
     fast, df = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, max_num=max_num, seed=seed,
                                              return_debug=True)
     assert torch.isfinite(fast).all()
-    # the default mode against the literal counts of the same draw: edge votes only (tests/test_fast_mode_parity.py
-    # holds the full set of fast-mode bars)
-    assert int((df["counts"] - counts_l).abs().max()) <= 2
+    # the default (exact) mode against the literal counts of the same draw: the reference's integers, on every shape
+    assert df["mode"] == "exact"
+    assert torch.equal(df["counts"], counts_l)
+    assert torch.equal(df["win"], dbg["win"])
 
 
 def test_concurrent_streams_reproduce_serial_results():

@@ -8,6 +8,12 @@ allocation that was used to the top and never with one granule more.
     python tools/check_kernel_resources.py            # compiles both sources to assembly (hipcc -S) and checks them
     python tools/check_kernel_resources.py a.s b.s
 
+Second rule: the kernels whose budget is set with `amdgpu_num_vgpr` (hypothesis_kernel, score_exact_kernel_*) rely on
+the gfx950 backend DOUBLING the attribute's literal (unified VGPR / AGPR file).  A compiler that stopped doing so would cap them at
+half their registers: massive spilling.  So for those kernels the allocation must be EXACTLY the one the occupancy plan assumes
+(EXPECTED_ALLOC: not more -- a wave per SIMD lost -- and not less), they must use more than half of it (a halved cap cannot) and
+none of them may spill more than a few dwords (`.amdhsa_private_segment_fixed_size` <= MAX_SCRATCH).
+
 Also reports the waves per SIMD each allocation permits (512 VGPRs per SIMD, granule 8).  Exit status 1 if a kernel lacks
 the slack.  tests/test_library_cpu.py runs it on every build of the CPU suite.
 """
@@ -19,6 +25,11 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SLACK = 8
+MAX_SCRATCH = 64   # bytes per lane a budgeted kernel may spill (the non-default two-pair RUNS variant spills three dwords); a halved cap spills hundreds
+# kernels with an `amdgpu_num_vgpr` budget: name pattern -> the allocation (VGPRs, granule-rounded) their occupancy plan assumes
+EXPECTED_ALLOC = [(r"\d+hypothesis_kernelI", 48), (r"\d+hypothesis_cull_kernelE", 64), (r"score_exact_kernel_[12]_", 112),
+                  (r"score_exact_kernel_4_", 144), (r"score_exact_kernel_8_\d_\d_1_0", 128), (r"score_exact_kernel_8_\d_\d_1_1", 136),
+                  (r"score_exact_kernel_8_\d_\d_2_", 168), (r"score_cull_kernel", 136)]
 
 
 def compile_to_asm(src, out):
@@ -36,11 +47,13 @@ def kernels(text):
         name = m.group(1)
         desc = text[m.start():text.index(".end_amdhsa_kernel", m.start())]
         nfv = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", desc).group(1))
+        m2 = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", desc)
+        scratch = int(m2.group(1)) if m2 else 0
         i = text.index(name + ":")
         body = text[i:text.index(".Lfunc_end", i)]
         body = "\n".join(l.split(";")[0] for l in body.splitlines())  # comments may mention registers
         used = [int(x) for x in re.findall(r"\bv(\d+)\b", body)] + [int(b) for _, b in re.findall(r"\bv\[(\d+):(\d+)\]", body)]
-        out.append((name, nfv, max(used) if used else -1))
+        out.append((name, nfv, max(used) if used else -1, scratch))
     return out
 
 
@@ -63,14 +76,20 @@ def main(argv):
     bad = 0
     n = 0
     for t in texts:
-        for name, nfv, vmax in kernels(t):
+        for name, nfv, vmax, scratch in kernels(t):
             n += 1
             slack = nfv - (vmax + 1)
             alloc = (nfv + 7) // 8 * 8
             flag = "" if slack >= SLACK else "   <-- uses its last granule: raise PVNET_SPARE_VGPRS"
             bad += slack < SLACK
+            for pat, want in EXPECTED_ALLOC:
+                if re.search(pat, name):
+                    if alloc != want or vmax + 1 <= want // 2 or scratch > MAX_SCRATCH:
+                        flag += f"   <-- budgeted kernel: expected {want} VGPRs allocated, more than {want // 2} used, no scratch (got {alloc}, {vmax + 1}, {scratch} B)"
+                        bad += 1
+                    break
             print(f"{short(name):58s} uses v0..v{vmax:<3d} allocates {alloc:3d} (slack {slack:3d}, {min(8, 512 // alloc)} waves/SIMD){flag}")
-    print(f"checked {n} kernels, {bad} without a spare granule")
+    print(f"checked {n} kernels, {bad} without a spare granule / off their register budget")
     return 1 if bad or n == 0 else 0
 
 

@@ -1,95 +1,31 @@
-"""Development aid: random configurations with the launch knobs flipped at random --
+"""Development aid: thousands of random configurations with the launch knobs flipped at random (the cases live in
+tests/fuzz_cases.py; tests/test_fuzz_gpu.py runs 200 of them in the GPU suite) --
   literal HIP path vs the C oracle: winners and their counts must be exact;
   EXACT mode (the default) vs literal: every hypothesis, every count, every winner must be EQUAL, key-points within 1e-3 px;
   approximate mode vs literal: counts within 2 votes up to thresh 0.999.
-Random field scales, un-normalised directions, zero / tiny directions, all mask dtypes, thinning, both cell sizes.
     python tools/fuzz_parity.py [cases [first_case]]   (MI355X)"""
 import os
 import sys
 
-import numpy as np
-import torch
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import cref, ransac_voting_oracle as O  # noqa: E402
-from pvnet_amd import synth, voting  # noqa: E402
+from tests import fuzz_cases as F  # noqa: E402
 
-dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 START = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # first case (cases are seeded by their number)
-KNOBS = {"PVNET_SCORE_XCD": ["0", "1"], "PVNET_SCORE_ATOMIC": ["0", "1"], "PVNET_SCORE_WGS_PER_CU": ["-1", "0", "2", "8", "12"],
-         "PVNET_COMPACT_KG": ["1", "3", "9"], "PVNET_EXACT_FOLD": ["-1", "0", "1"],
-         "PVNET_SCORE_ACC": ["-1", "1", "2"], "PVNET_SCORE_RUNS": ["-1", "0", "1"]}
-bad_exact = 0
-bad = 0
+bad_exact = bad = 0
 worst = {}
 for case in range(START, N):
-    rng = np.random.default_rng(5000 + case)
-    for k, vals in KNOBS.items():
-        os.environ[k] = str(rng.choice(vals))
-    voting.reload_tuning()
-    h, w = int(rng.integers(16, 300)), int(rng.integers(16, 400))
-    vn = int(rng.integers(1, 14))
-    hn = int(rng.choice([8, 31, 64, 100, 128, 257, 512, 1000, 1500]))
-    b = int(rng.integers(1, 6))
-    radius = int(rng.integers(3, max(4, min(h, w) // 2)))
-    thresh = float(rng.choice([0.5, 0.9, 0.99, 0.999, 0.9999]))
-    max_num = int(rng.choice([30000, 1000, 150, 40, 7]))
-    mdt = rng.choice(["int64", "uint8", "int32"])
-    scale = float(rng.choice([1.0, 1.0, 2.0 ** -3, 2.0 ** 9]))
-    mask, planar, _ = synth.make_batch(b, first_index=9000 + 3 * case, h=h, w=w, vn=vn, radius=radius,
-                                       noise=bool(rng.integers(0, 2)), background=str(rng.choice(["normal", "zeros"])),
-                                       mask_dtype=getattr(np, mdt))
-    planar = (planar * np.float32(scale)).astype(np.float32)
-    unnorm = rng.integers(0, 3) == 0
-    if unnorm:  # un-normalised field: a random positive factor per pixel and plane pair, some of them ~0
-        fac = np.exp(rng.normal(0.0, 3.0, size=(b, 1, h, w))).astype(np.float32)
-        fac[rng.random(fac.shape) < 0.02] = np.float32(rng.choice([0.0, 1e-7, 1.0000001e-6, 1e-5]))
-        planar = (planar.reshape(b, vn, 2, h, w) * fac[:, :, None]).reshape(b, 2 * vn, h, w).astype(np.float32)
-    vnp = synth.planar_to_vertex_view(planar)
-    m = torch.from_numpy(mask).to(dev)
-    p = torch.from_numpy(planar).to(dev)
-    v = synth.planar_to_vertex_view(p) if rng.integers(0, 2) else synth.planar_to_vertex_view(p).contiguous()
-    seed = int(rng.integers(0, 2 ** 40))
-    out, dbg = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, max_num=max_num, seed=seed, literal=True,
-                                             return_debug=True)
-    counts_l, win_l, nch = dbg["counts"].clone(), dbg["win"].cpu().numpy().copy(), dbg["nchunks"].cpu().numpy().copy()
-    ref, wi, wc = cref.vote_v3(O.foreground(mask), vnp, hn, thresh, max_num=max_num, seed=seed, return_winners=True)
-    live = nch > 0
-    ok = np.array_equal(win_l[:, :, 0][live], wi[live]) and np.array_equal(win_l[:, :, 1][live], wc[live])
-    hyp_l, out_l = dbg["hyp"].clone(), out.clone()
-    ex, de = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, max_num=max_num, seed=seed, return_debug=True,
-                                           concurrent=bool(rng.integers(0, 2)))  # (the in-flight variant: contiguous item runs)
-    same = (de["hyp"].cpu().numpy().tobytes() == hyp_l.cpu().numpy().tobytes() and torch.equal(de["counts"], counts_l)
-            and np.array_equal(de["win"].cpu().numpy(), win_l))
-    okpx = torch.isfinite(out_l).all(-1) & (out_l.abs() < 1e5).all(-1)
-    px = float((ex - out_l)[okpx].abs().max()) if okpx.any() else 0.0
-    if not same or px > 1e-3 * max(1.0, float(out_l[okpx].abs().max()) / 100 if okpx.any() else 1.0):
+    r = F.run_case(case)
+    worst[r["thresh"]] = max(worst.get(r["thresh"], 0), r["approx_diff"])
+    if not r["ok_exact"]:
         bad_exact += 1
-        print("EXACT-MODE MISMATCH case", case, dict(h=h, w=w, vn=vn, hn=hn, b=b, radius=radius, thresh=thresh, max_num=max_num,
-                                                     mdt=mdt, scale=scale), {k: os.environ[k] for k in KNOBS},
-              "counts differ:", int((de["counts"] != counts_l).sum()), "max", int((de["counts"] - counts_l).abs().max()),
-              "px", px, flush=True)
-    fast, df = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, max_num=max_num, seed=seed, approx=True,
-                                             return_debug=True)
-    cd = 0 if unnorm else int((df["counts"] - counts_l).abs().max())
-    worst[thresh] = max(worst.get(thresh, 0), cd)
-    fin = bool(torch.isfinite(fast).all())
-    # fast vs literal drift apart as thresh -> 1 (the reference's float32 cos is flat there) and with the number of pixels a
-    # hypothesis is tested on: at 0.999 and 30 000 pixels literal is off by up to 3 votes against float64 arithmetic where fast is
-    # off by 0-1 (tools/experiments/fuzz_case_check.py 1046)
-    tn_max = int(df["tn"].max())
-    lim = 2 if thresh <= 0.99 else (2 + tn_max // 10000 if thresh <= 0.999 else 12)
-    # (un-normalised fields: the approximate mode stores |u| < 1e-6 as zero records, so its hypotheses may differ -- not compared)
-    if not ok or cd > lim or not fin:
+        print("EXACT-MODE MISMATCH", r["desc"], flush=True)
+    if not r["ok_literal"] or r["approx_diff"] > r["approx_limit"] or not r["finite"]:
         bad += 1
-        print("MISMATCH case", case, dict(h=h, w=w, vn=vn, hn=hn, b=b, radius=radius, thresh=thresh, max_num=max_num, mdt=mdt,
-                                          scale=scale), {k: os.environ[k] for k in KNOBS}, "winners_ok", ok,
-              "max count diff fast-literal", cd, "finite", fin, flush=True)
+        print("MISMATCH", r["desc"], "winners_ok", r["ok_literal"], "max count diff approx-literal", r["approx_diff"], "finite",
+              r["finite"], flush=True)
     if (case + 1) % 100 == 0:
         print(f"... case {case + 1}: exact != literal {bad_exact}, other failures {bad}", flush=True)
-for k in KNOBS:
-    os.environ.pop(k, None)
-voting.reload_tuning()
-print(f"fuzz done: {N} cases; exact mode != literal in {bad_exact} cases; literal-vs-C-oracle / approx-bound failures {bad}; "
+F.clear_knobs()
+print(f"fuzz done: cases {START}..{N - 1}; exact mode != literal in {bad_exact} cases; literal-vs-C-oracle / approx-bound failures {bad}; "
       f"worst approx-vs-literal count difference per threshold: {dict(sorted(worst.items()))}")
