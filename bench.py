@@ -48,6 +48,9 @@ Besides the contract's fields the line carries
   approx_mode   votings/s of PVNET_F_APPROX (the round-1/2 "fast" mode: no rounding-band re-evaluation, counts within a few
                 votes of the reference's) on the same inputs and streams -- what exactness costs.
   literal_mode  votings/s of PVNET_F_LITERAL (the reference's float32 order for every pair on the VALU) on the same inputs.
+  secondary     the configurations the reference itself calls with (its default thresh 0.999, ~29.5 k-pixel objects, the two
+                single-frame call sites of tools/demo.py and tools/train_linemod.py): votings/s on one stream, the scoring stage's
+                time and each call's own counts-equal-literal check.  Never part of `value`.
   cpu_baseline  the plain-C restatement (oracle) timed on a bounded sample of the same workload.
 """
 import argparse
@@ -110,6 +113,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-parity", action="store_true", help="skip the post-run parity check of the timed mode")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` block (the reference's own call configurations, a few seconds)")
     ap.add_argument("--approx", action="store_true",
                     help="DEVELOPMENT: time PVNET_F_APPROX as the main mode (the line's `mode` says so); for A/B runs against "
                          "earlier rounds, whose default mode this was")
@@ -427,6 +432,73 @@ def parity_check(sets, rank, o64_images=BATCH, ref_images=8, max_sets=2):
     return out
 
 
+def secondary_block(sets, rank, dev, budget_s=3.0):
+    """The configurations the REFERENCE itself calls with, in the driver's line -- not the headline, never
+    `value`: (1) the reference's default inlier_thresh 0.999 (ransac_voting_gpu.py:514) on the headline's batch; (2) objects of
+    ~29.5 k pixels (R = 97, just under max_num = 30 000); (3) tools/demo.py:55's call, one frame, 512 hypotheses; (4)
+    tools/train_linemod.py:106's call, one frame, 128 hypotheses, max_num = 100.  Each: the DEFAULT (exact) mode through a
+    prepared VotePlan on ONE stream, calls issued back to back (what a caller with one frame in flight sees), the scoring stage's
+    own time from an event pair, and the call's own parity: all inlier counts and winners against literal mode on the same
+    inputs and draw.  Time-bounded: the timed calls of the four entries together stay below `budget_s` seconds of GPU time."""
+    out = {"note": "one stream, default (exact) mode, VotePlan (no per-call allocation); parity = this call's counts / winners "
+                   "against literal mode (the reference's float32 order for every pair) on the same inputs and draw",
+           "entries": {}}
+    t_all = time.perf_counter()
+
+    def entry(name, ref, m, v, hn, thresh, max_num, steps):
+        b = int(m.shape[0])
+        plan = voting.VotePlan(m, v, hn, inlier_thresh=thresh, max_num=max_num)
+        for i in range(5):
+            plan(m, v, seed=i)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        plan(m, v, seed=0)
+        torch.cuda.synchronize(dev)
+        one = max(time.perf_counter() - t0, 1e-5)
+        steps = int(max(10, min(steps, budget_s / 4 / one)))   # a quarter of the budget each
+        t0 = time.perf_counter()
+        for i in range(steps):
+            plan(m, v, seed=SEED0 + i)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        _, dbg, st = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, max_num=max_num, seed=SEED0,
+                                                   image_offset=rank * BATCH, return_debug=True, stage_times=True, concurrent=False)
+        counts, win = dbg["counts"].clone(), dbg["win"].clone()
+        tn = float(dbg["tn"].float().mean())
+        _, dl = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, max_num=max_num, seed=SEED0,
+                                              image_offset=rank * BATCH, literal=True, return_debug=True)
+        pairs = hn * VN * tn * b
+        out["entries"][name] = {
+            "reference_call": ref, "batch": b, "hn": hn, "inlier_thresh": thresh, "max_num": max_num, "mean_kept_px": tn,
+            "us_per_call": dt * 1e6, "votings_per_s": b / dt, "calls_timed": steps,
+            "score_us": st["score"] * 1e3, "pair_tests_per_s_in_score": pairs / max(st["score"] * 1e-3, 1e-9),
+            "stage_us": {k: x * 1e3 for k, x in st.items()},
+            "counts_equal_literal": int((counts == dl["counts"]).all(2).sum()), "keypoints_checked": b * VN,
+            "winners_equal_literal": int((win == dl["win"]).all(2).sum()),
+            "pass": bool((counts == dl["counts"]).all() and (win == dl["win"]).all())}
+
+    m0, v0, _, _ = sets[0]
+    entry("thresh_0.999_batch32", "ransac_voting_gpu.py:514 (the layer's default inlier_thresh)", m0, v0, HN, 0.999, 30000, 400)
+    mask, planar, _ = synth.make_batch(BATCH, first_index=7000, h=H, w=W, vn=VN, radius=97, noise=True, background="normal")
+    mb = torch.from_numpy(mask).to(dev)
+    vb = synth.planar_to_vertex_view(torch.from_numpy(planar).to(dev))
+    entry("object_29k_px_batch32", "SURVEY 8(d) stress shape: R = 97, tn ~ 29.5 k, just under max_num", mb, vb, HN, THRESH, 30000, 100)
+    del mb, vb
+    mask, planar, _ = synth.make_batch(1, first_index=7100, h=H, w=W, vn=VN, radius=27, noise=True, background="normal")
+    m1 = torch.from_numpy(mask).to(dev)
+    v1 = synth.planar_to_vertex_view(torch.from_numpy(planar).to(dev))
+    entry("demo_call_site_b1_hn512", "tools/demo.py:55: ransac_voting_layer_v3(mask, vertex, 512, inlier_thresh=0.99)",
+          m1, v1, 512, 0.99, 30000, 2000)
+    mask, planar, _ = synth.make_batch(1, first_index=7101, h=H, w=W, vn=VN, radius=40, noise=True, background="normal")
+    m2 = torch.from_numpy(mask).to(dev)
+    v2 = synth.planar_to_vertex_view(torch.from_numpy(planar).to(dev))
+    entry("eval_call_site_b1_hn128_max100", "tools/train_linemod.py:106: ransac_voting_layer_v3(mask, vertex, 128, "
+          "inlier_thresh=0.99, max_num=100)", m2, v2, 128, 0.99, 100, 2000)
+    out["pass"] = all(e["pass"] for e in out["entries"].values())
+    out["wall_s"] = time.perf_counter() - t_all
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------ main
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
@@ -605,8 +677,7 @@ def main(argv=None):
     # when the recorded regions begin)
     with GpuSampler(local) as sampler:
         pre = regions(nstreams, mode=MAIN, n=int(os.environ.get("BENCH_UNRECORDED", "12")) if a.steps < 200 else 1)
-        if os.environ.get("BENCH_SHOW_UNRECORDED") == "1":
-            print("unrecorded regions (k votings/s):", [round(world * BATCH * a.steps / r[0] / 1e3, 1) for r in pre], file=sys.stderr)
+        pre_rates = [world * BATCH * a.steps / r[0] for r in pre]   # (in the line, not only on stderr)
         sampler.samples.clear()
         runs = regions(nstreams, mode=MAIN)          # the headline: R regions of K steps, independent batches on S streams
     dts = [r[0] for r in runs]
@@ -684,6 +755,9 @@ def main(argv=None):
                                 "and ms_per_step are the MEDIAN region; before them the same region runs unrecorded (when "
                                 "K < 200: twelve times) so that none of the recorded ones "
                                 "sees the ramp after the device's idle phases",
+                        "unrecorded_values": pre_rates,
+                        "unrecorded_note": "rates of the regions run BEFORE the recorded ones (same form, same clock): rounds 1-3 "
+                                           "recorded from the first region on, so their BENCH numbers include the ramp these show",
                         "gpu": sampler.summary()},
             "mode": "APPROX (--approx, development A/B only)" if a.approx else
                     "exact (library default): inlier counts and winners equal the reference kernels'",
@@ -770,6 +844,11 @@ def main(argv=None):
                 res["parity"] = parity_check(sets, rank)
             except Exception as e:  # a failing checker is reported, it must not hide the measurement
                 res["parity"] = {"pass": False, "error": f"{type(e).__name__}: {e}"}
+        if not a.no_secondary:
+            try:
+                res["secondary"] = secondary_block(sets, rank, dev)
+            except Exception as e:  # reported, never allowed to take the measured line down
+                res["secondary"] = {"pass": False, "error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(sets, a.cpu_seconds)

@@ -19,8 +19,13 @@ __device__ __forceinline__ int wave_reduce_add(int v) {
 #ifndef VOL
 #define VOL
 #endif
+#ifdef V_WPE1   // round 5: the same code under amdgpu_waves_per_eu(1, 1) -- an occupancy HINT to the
+#define WPE_ATTR __attribute__((amdgpu_waves_per_eu(1, 1)))   // compiler; the dispatcher still co-schedules what fits
+#else
+#define WPE_ATTR
+#endif
 template <int K2_KG>
-__global__ __launch_bounds__(256) void compact_kernel(Params P) {
+__global__ __launch_bounds__(256) WPE_ATTR void compact_kernel(Params P) {
 #ifdef V_SPARE
     asm volatile("" ::: "v31");  // the rule: one unused VGPR granule beyond what the kernel uses (24 -> 32 allocated)
 #endif
