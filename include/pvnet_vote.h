@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PVNET_VOTE_ABI_VERSION 7
+#define PVNET_VOTE_ABI_VERSION 8
 
 /* negative library error codes */
 #define PVNET_E_BADARG      (-1)   /* null pointer / non-positive size / unsupported dtype or stride */
@@ -122,6 +122,14 @@ typedef struct PvnetVoteLayout {
     int32_t nseg;           /* ceil(words / 64)                                                             */
     int32_t wg_g, wg_s;     /* a scoring workgroup covers wg_g hypothesis groups x wg_s chunks (wg_g*wg_s=4) */
     int32_t reserved_;      /* 1: fast mode scores on the matrix pipe (score_mfma_kernel), 0: VALU kernel                */
+    /* ABI 8 -- disc culling of the exact mode (pvnet_vote.hip: hypothesis_cull_kernel / score_exact_kernel_cull; PVNET_SCORE_CULL).
+     * Empty (cull = 0) unless the layout scores 8 hypothesis tiles per wave on 256-pixel work items with hn_pad <= 4096.        */
+    int32_t cull;           /* 1: exact-mode calls of this layout sort each key-point's hypotheses along a Hilbert curve and
+                               score only the (pixel, hypothesis tile) pairs whose outcome the tile's disc does not fix        */
+    size_t off_perm;        /* int32  [b][vn][hn_pad]      sorted position -> caller's hypothesis index (>= hn: padding)        */
+    size_t off_hyps;        /* float2 [b][vn][hn_pad]      hypotheses in sorted order                                          */
+    size_t off_cnts;        /* int32  [b][vn][hn_pad]      inlier counts in sorted order (`counts` holds them in CALLER order)  */
+    size_t off_hypc;        /* uint4  [b][vn][hn_pad/32][2] B column of every tile's centre, then float [b][vn][hn_pad/32] g    */
 } PvnetVoteLayout;
 
 /* Host-only: fills *out for a problem size.  max_num as passed to pvnet_vote_v3. */

@@ -68,6 +68,9 @@ constexpr int SEG_WORDS = 64;          // a segment = 64 words = 4096 pixels: th
 #ifndef PVNET_SMALL_PRIO
 #define PVNET_SMALL_PRIO 3
 #endif
+#ifndef PVNET_CULL_DEFAULT
+#define PVNET_CULL_DEFAULT 0   // what PVNET_SCORE_CULL = -1 (not set) means: 1 = disc culling where the layout supports it
+#endif
 // the small latency-bound stages ask for issue priority over the co-resident scoring waves of other batches (s_setprio 3).
 // Round 1 measured nothing from it (nothing WAS resident beside the scoring kernel); since round 3 their workgroups share
 // SIMDs with the one-accumulator scoring kernel of concurrent callers, and their dependent chains finishing sooner is worth
@@ -98,6 +101,7 @@ constexpr int K2_WORDS_PER_BLOCK = SEG_WORDS;
 // probability down to 1/64, sixteen steps per octave below (round 4; rounds 2-3: the top ten bits only)
 constexpr int THIN_BINS = (PVNET_THIN_LAST + 1 + 127) / 128 * 128;   // 1536: histogram length, an EVEN number of bins per lane
 constexpr int PAD = 8;                 // scoring consumes records 8 at a time; tails are padded with sentinels
+constexpr int TILE_U4_ = 128;          // uint4 per 32-pixel A tile of the matrix-pipe kernels (= TILE_U4 below)
 
 struct VoteParams {
     const void* mask;
@@ -133,6 +137,13 @@ struct VoteParams {
     int32_t* win;
     float* out;
     int32_t* status;
+    // disc culling (round 5; section "K4 -- disc culling" below): hypotheses sorted along a Hilbert curve per key-point
+    int cull;            // 1: this call scores with score_exact_kernel_cull (exact mode, 8 tiles per wave, 256-pixel items)
+    int32_t* perm;       // [b][vn][hn_pad] sorted position -> caller's hypothesis index
+    float2* hyps;        // [b][vn][hn_pad] the hypotheses in sorted order (literal re-evaluation of flagged cells)
+    int32_t* cnts;       // [b][vn][hn_pad] inlier counts in sorted order (K4 accumulates; K5 returns them to caller order)
+    uint4* hypc;         // [b][vn][hn_pad / 32][2] B column of every 32-hypothesis tile's CENTRE, scaled by 1 / (radius + band)
+    float* hypg;         // [b][vn][hn_pad / 32]    g = radius term / (radius term + band term) of the tile (0: every pixel uncertain)
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -322,10 +333,10 @@ __device__ __forceinline__ float band_rho(int tn) {
 __device__ __forceinline__ int32_t* band_origin_ptr(const VoteParams& P, size_t bk) {
     return P.ctrl + (size_t)(P.b + 1) * CTRL_STRIDE + 2 * bk;
 }
-__device__ __forceinline__ void b_col_exact(float hxo, float hyo, float rho, float kband, uint4& lo, uint4& hi) {
-    const float R = __builtin_sqrtf(fmaf(hxo, hxo, hyo * hyo)) * 1.000001f;
-    float s = BAND_TARGET / ((R + rho) * kband);
-    s = __uint_as_float(__float_as_uint(s) & 0xFFFF0000u);  // round down to bf16: s * (c0 + c1 + c2) stays exact
+// the column of the point o + (hxo, hyo) at scale s (a bf16 value): s (hxo, hyo) as three bf16 parts each, s in the constant slots,
+// 1 in the spare 16th slot (against which dead rows carry their -4); s <= 0 / NaN, or a point too far: the ZERO column -- x = 0
+// for every live pixel, which the exact kernel flags (decided literally) and the culling kernel's disc test calls uncertain
+__device__ __forceinline__ void b_col_scaled(float hxo, float hyo, float R, float s, uint4& lo, uint4& hi) {
     const uint32_t one = 0x3F80u;
     if (!(R < BAND_FAR) || !(s > 0.f)) {  // too far, Inf or NaN: x = 0 for every live pixel -> decided literally
         lo = make_uint4(0u, 0u, 0u, 0u);
@@ -338,11 +349,21 @@ __device__ __forceinline__ void b_col_exact(float hxo, float hyo, float rho, flo
     lo = make_uint4(q0, q0, q1, q0);
     hi = make_uint4(q2, q1, pk(sb, sb), pk(sb, one));
 }
+__device__ __forceinline__ float bf16_floor(float s) {   // round down to bf16: s * (c0 + c1 + c2) stays exact
+    return __uint_as_float(__float_as_uint(s) & 0xFFFF0000u);
+}
+__device__ __forceinline__ void b_col_exact(float hxo, float hyo, float rho, float kband, uint4& lo, uint4& hi) {
+    const float R = __builtin_sqrtf(fmaf(hxo, hxo, hyo * hyo)) * 1.000001f;
+    b_col_scaled(hxo, hyo, R, bf16_floor(BAND_TARGET / ((R + rho) * kband)), lo, hi);
+}
 // per-pixel rows of dt' and cr', the direction normalised to |M| = sigma <= rho / (rho + r)
+// (mu: an upper bound of the row's scale |M| <= rho / (rho + r) -- what the disc test of the culling kernel needs per pixel;
+// 1 for dead and zero rows, whose x does not depend on it)
 __device__ __forceinline__ void a_rows_exact(float4 q, float tau, float ox, float oy, float rho, uint4& alo, uint4& ahi,
-                                             uint4& blo, uint4& bhi) {
+                                             uint4& blo, uint4& bhi, float& mu) {
     const uint32_t never = 0xC080u;  // bf16 -4 in the spare slot of the dt' row: x = -4
     alo = ahi = blo = bhi = make_uint4(0u, 0u, 0u, 0u);
+    mu = 1.f;
     const float m = fmaxf(fabsf(q.z), fabsf(q.w));
     const uint32_t e = (__float_as_uint(m) >> 23) & 0xFFu;
     const bool finite = fabsf(q.z) <= 3.4028235e38f && fabsf(q.w) <= 3.4028235e38f;  // false for NaN and Inf
@@ -366,8 +387,10 @@ __device__ __forceinline__ void a_rows_exact(float4 q, float tau, float ox, floa
     const float g = __builtin_amdgcn_rsqf(fmaf(u1y, u1y, u1x * u1x));
     const float cx = q.x - ox, cy = q.y - oy;                   // exact: integer pixel coordinates
     const float r = __builtin_amdgcn_sqrtf(fmaf(cy, cy, cx * cx));            // (v_sqrt_f32 / v_rcp_f32: 1 ulp each --
-    const float gs = g * rho * __builtin_amdgcn_rcpf(rho + r) * 0.9997f;      //  an upper bound is all that is needed)
-    // |M| = |u1| gs <= rho / (rho + r)
+    const float sig = rho * __builtin_amdgcn_rcpf(rho + r);
+    const float gs = g * sig * 0.9997f;                                       //  an upper bound is all that is needed)
+    // |M| = |u1| gs <= rho / (rho + r)  (and < sig as computed: the 3e-4 of slack is far above the roundings of g, sig and M)
+    mu = sig;
     const float Mx = u1x * gs, My = u1y * gs;
     const float Tx = tau * Mx, Ty = tau * My;
     const float Ec = fmaf(cx, My, -cy * Mx);                    // cr = hx My - hy Mx - Ec
@@ -724,6 +747,8 @@ __device__ __forceinline__ void plan_image(const VoteParams& P, int bi) {
             P.ctrl[P.b * CTRL_STRIDE + 6] = P.layout_fp;  // which layout the offsets of this workspace follow (epilogues check)
             P.ctrl[P.b * CTRL_STRIDE + 4] = 0;     // exact mode, PVNET_F_BAND_STATS: flagged cells / literal tests
             P.ctrl[P.b * CTRL_STRIDE + 5] = 0;
+            P.ctrl[P.b * CTRL_STRIDE + 1] = 0;     // disc culling, PVNET_F_BAND_STATS: fine steps executed / steps of the full kernel
+            P.ctrl[P.b * CTRL_STRIDE + 7] = 0;
         }
     }
     const int HQ = P.hgroups / P.wg_g, nchg = (nch + P.wg_s - 1) / P.wg_s;
@@ -886,6 +911,250 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(20))) void hypo
         o[0] = lo;
         o[1] = hi;
     }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K3 for the disc-culling scoring kernel (round 5): one workgroup per (image, key-point) generates the key-point's hypotheses
+// (the same draws, the same arithmetic, the same caller-order `hyp` array as hypothesis_kernel), SORTS them along a Hilbert curve
+// about the band origin so that every 32 consecutive ones -- one MFMA hypothesis tile -- lie close together, and describes each
+// tile by a disc: centre q (bounding-box centre), radius rho_T.  The scoring kernel tests every pixel ONCE against the centre of
+// each tile (one MFMA pair per 32 pixels x 32 tiles) and only gathers the pixels whose vote is not the same for the whole disc.
+//   sorted order : hypb (B columns), hyps (raw hypotheses, for the literal re-evaluation), cnts (counts), perm (-> caller index)
+//   per tile     : hypc = the B column of the centre at scale s' = 0.9 / (G + E), hypg = g = G / (G + E), with
+//                  G = rho_T / thresh   (|m(h) - m(q)| <= |h - q| / cos theta0: the margin's Lipschitz constant) and
+//                  E = kband (R_q + rho_T + rho)   (rounding band of every hypothesis of the disc + the matrix pipe's own error)
+// A pixel i with row scale |M_i| <= mu_i is CERTAIN for the tile when |x'| >= 1 - g (1 - mu_i), x' = s' |M_i| m_i(q) as the two
+// MFMAs return it: then |m_i(q)| > rho_T / thresh + band, so m_i has one sign on the whole disc and the reference's float32 test
+// agrees with it for every hypothesis of the tile (derivation: DESIGN.md section 4, "disc culling").
+// Padding hypotheses (>= hn) sort to the end; a tile without a real hypothesis is never scored.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int CULL_NPX = 256;              // pixels per work item of the culling kernel: 8 pixel tiles, list entries are 16-bit
+constexpr int CULL_MAX_HN = 4096;          // hypotheses per key-point the sort handles in LDS (hn_pad)
+constexpr int CULL_DEAD = 8 * TILE_U4_;    // uint4 index of the dead A row behind the item's 8 tiles (x = -4: no vote, no flag)
+
+// position of (x, y) on the Hilbert curve of a 2^bits x 2^bits grid (consecutive positions are neighbouring cells)
+__device__ __forceinline__ uint32_t hilbert_index(uint32_t x, uint32_t y, int bits) {
+    uint32_t d = 0;
+    for (uint32_t sft = 1u << (bits - 1); sft > 0; sft >>= 1) {
+        const uint32_t rx = (x & sft) ? 1u : 0u, ry = (y & sft) ? 1u : 0u;
+        d += sft * sft * ((3u * rx) ^ ry);
+        if (ry == 0u) {
+            if (rx == 1u) { x = ~x; y = ~y; }   // (only the bits below sft are looked at from here on)
+            const uint32_t t = x; x = y; y = t;
+        }
+    }
+    return d;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(28))) void hypothesis_cull_kernel(VoteParams P) {
+    PVNET_SPARE_VGPRS(63);
+    small_stage_prio();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // blocks of image bi on XCD bi % 8 (its records pass through one L2, as in hypothesis_kernel); vn + 1 blocks per image, the last plans
+    const int nb = P.vn + 1;
+    const int slot = blockIdx.x >> 3;
+    const int bi = (slot / nb) * 8 + (blockIdx.x & 7);
+    const int k = slot % nb;
+    if (bi >= P.b) return;
+    if (k == P.vn) {
+        plan_image(P, bi);
+        return;
+    }
+    const int tid = threadIdx.x;
+    const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
+    const bool live = P.ctrl[bi * CTRL_STRIDE + C_TN0] >= P.min_num && tn > 0;  // gates of :531-534
+    const size_t bk = (size_t)bi * P.vn + k;
+    float2* s_h = reinterpret_cast<float2*>(smem);                  // [hn_pad] hypotheses, caller order
+    uint32_t* s_key = reinterpret_cast<uint32_t*>(s_h + P.hn_pad);  // [n2] (Hilbert position << idxbits) | caller index
+    int n2 = 1;
+    while (n2 < P.hn_pad) n2 <<= 1;
+    const int idxbits = 31 - __clz(n2);
+    const int cbits = (32 - idxbits) >> 1;   // bits per coordinate of the key: 11 at 1 024 hypotheses (+-128 px in 1/8 px), 10 at 4 096
+    constexpr int NCAND = 8;
+    __shared__ float s_cand[NCAND * 2];
+    __shared__ float s_med[2];
+    __shared__ int s_org[2];
+    const float rho = band_rho(tn);
+
+    // ---- the band origin of this key-point: the same estimate as hypothesis_kernel's (eight fixed pixel pairs, component-wise median,
+    //      the median pixel when the candidates scatter or fewer than three are usable)
+    int pm = 0;
+    if (live) pm = P.pix[(size_t)bi * P.cap + tn / 2];
+    if (tid < NCAND) {
+        float cx = __uint_as_float(0x7FC00000u), cy = cx;   // NaN = no candidate
+        if (live) {
+            const int ta = (int)(((long long)(2 * tid + 1) * tn) >> 4);
+            int tb = ta + tn / 2;
+            tb = tb >= tn ? tb - tn : tb;
+            const float4 q0 = P.rec[bk * P.cap + ta], q1 = P.rec[bk * P.cap + tb];
+            float hx0, hy0;
+            hyp_intersect(q0.z, q0.w, q0.x, q0.y, q1.z, q1.w, q1.x, q1.y, hx0, hy0);
+            if ((hx0 != 0.f || hy0 != 0.f) && fabsf(hx0) < 1048576.f && fabsf(hy0) < 1048576.f) { cx = hx0; cy = hy0; }
+        }
+        s_cand[tid * 2] = cx;
+        s_cand[tid * 2 + 1] = cy;
+    }
+    // ---- this key-point's hypotheses (kernel.cu:11-49), caller order: thread t takes h = t, t + 256, ...
+    for (int h = tid; h < P.hn_pad; h += 256) {
+        float hx = 0.f, hy = 0.f;
+        if (live && h < P.hn) {
+            const int i = h * P.vn + k;   // the draw's index in the reference's [hn, vn, 2] layout
+            int t0, t1;
+            if (P.idxs) {
+                t0 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2];
+                t1 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2 + 1];
+                t0 = t0 < 0 ? 0 : (t0 >= tn ? tn - 1 : t0);  // memory safety only; valid idxs are untouched
+                t1 = t1 < 0 ? 0 : (t1 >= tn ? tn - 1 : t1);
+            } else {
+                const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_HYP, (uint32_t)(P.image_base + bi));
+                t0 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u), (uint32_t)tn);
+                t1 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u + 1u), (uint32_t)tn);
+            }
+            const float4 q0 = P.rec[bk * P.cap + t0], q1 = P.rec[bk * P.cap + t1];
+            hyp_intersect(q0.z, q0.w, q0.x, q0.y, q1.z, q1.w, q1.x, q1.y, hx, hy);
+        }
+        s_h[h] = make_float2(hx, hy);
+        if (h < P.hn) P.hyp[bk * P.hn_pad + h] = make_float2(hx, hy);
+    }
+    __syncthreads();
+    {   // median by rank, as in hypothesis_kernel (one key-point here)
+        const int j = tid % NCAND;
+        const bool mine = tid < NCAND;
+        int n = 0;
+        if (mine) {
+            int rx = 0, ry = 0;
+            const float vx = s_cand[2 * j], vy = s_cand[2 * j + 1];
+            for (int m2 = 0; m2 < NCAND; ++m2) {
+                const float ux = s_cand[2 * m2], uy = s_cand[2 * m2 + 1];
+                n += ux == ux ? 1 : 0;
+                rx += (ux < vx || (ux == vx && m2 < j)) ? 1 : 0;
+                ry += (uy < vy || (uy == vy && m2 < j)) ? 1 : 0;
+            }
+            if (vx == vx && rx == n / 2) s_med[0] = vx;
+            if (vy == vy && ry == n / 2) s_med[1] = vy;
+        }
+        __syncthreads();
+        if (mine && n >= 3) {
+            const float mx = s_med[0], my = s_med[1];
+            const float dj = fmaxf(fabsf(s_cand[2 * j] - mx), fabsf(s_cand[2 * j + 1] - my));
+            int rank = 0;
+            for (int m2 = 0; m2 < NCAND; ++m2) {
+                const float d2 = fmaxf(fabsf(s_cand[2 * m2] - mx), fabsf(s_cand[2 * m2 + 1] - my));
+                rank += (d2 < dj || (d2 == dj && m2 < j)) ? 1 : 0;
+            }
+            if (dj == dj && rank == n / 2) {
+                const float ro = rho * (1.f / 0.6f);
+                const float dist = fmaxf(fabsf(mx - (float)(pm % P.w)), fabsf(my - (float)(pm / P.w)));
+                const bool kp = (dj + rho) * (1.f + (dist + ro) / rho) < (dist + dj + rho) * (1.f + ro / rho);
+                s_org[0] = kp ? (int)rintf(mx) : pm % P.w;
+                s_org[1] = kp ? (int)rintf(my) : pm / P.w;
+            }
+        } else if (mine && j == 0) {   // fewer than three usable candidates
+            s_org[0] = pm % P.w;
+            s_org[1] = pm / P.w;
+        }
+        __syncthreads();
+    }
+    const float ox = (float)s_org[0], oy = (float)s_org[1];
+    if (tid == 0) {   // for the scoring kernel's staging (a_rows_exact)
+        int32_t* o = band_origin_ptr(P, bk);
+        o[0] = s_org[0];
+        o[1] = s_org[1];
+    }
+    // ---- sort keys: position on a Hilbert curve of 1/8-pixel cells about the origin; far and non-finite hypotheses clamp to the border
+    {
+        const float cells = (float)(1 << cbits);
+        for (int h = tid; h < n2; h += 256) {
+            uint32_t key = 0xFFFFFFFFu;
+            if (h < P.hn) {
+                const float2 hv = s_h[h];
+                const float fx = fminf(fmaxf((hv.x - ox) * 8.f + 0.5f * cells, 0.f), cells - 1.f);   // (NaN -> 0)
+                const float fy = fminf(fmaxf((hv.y - oy) * 8.f + 0.5f * cells, 0.f), cells - 1.f);
+                key = (hilbert_index((uint32_t)fx, (uint32_t)fy, cbits) << idxbits) | (uint32_t)h;
+            } else if (h < P.hn_pad) {
+                key = (0xFFFFFFFFu << idxbits) | (uint32_t)h;   // padding: behind every real hypothesis (ties broken by the index)
+            }
+            s_key[h] = key;
+        }
+    }
+    __syncthreads();
+    for (int kk = 2; kk <= n2; kk <<= 1)   // bitonic sort, ascending
+        for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+            for (int i = tid; i < n2; i += 256) {
+                const int ixj = i ^ jj;
+                if (ixj > i) {
+                    const uint32_t a = s_key[i], c = s_key[ixj];
+                    const bool up = (i & kk) == 0;
+                    if ((a > c) == up) { s_key[i] = c; s_key[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // ---- sorted outputs
+    const uint32_t imask = (uint32_t)n2 - 1u;
+    for (int p = tid; p < P.hn_pad; p += 256) {
+        const int j = (int)(s_key[p] & imask);
+        const bool real = j < P.hn;
+        const float2 hv = real ? s_h[j] : make_float2(0.f, 0.f);
+        P.perm[bk * P.hn_pad + p] = j;
+        P.hyps[bk * P.hn_pad + p] = hv;
+        P.cnts[bk * P.hn_pad + p] = 0;   // K4 accumulates into it
+        uint4 lo, hi;
+        if (real) {
+            b_col_exact(hv.x - ox, hv.y - oy, rho, P.kband, lo, hi);
+        } else {
+            lo = make_uint4(0u, 0u, 0u, 0u);
+            hi = make_uint4(0u, 0u, 0u, pk(0u, 0x3F80u));
+        }
+        uint4* o = P.hypb + (bk * P.hn_pad + p) * 2;
+        o[0] = lo;
+        o[1] = hi;
+    }
+    // ---- one disc per tile of 32 sorted hypotheses
+    const int ntl = P.hn_pad >> 5;
+    for (int T = tid; T < ntl; T += 256) {
+        float mnx = 3.0e38f, mny = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f;
+        bool bad = false;
+        int nreal = 0;
+        for (int e = 0; e < 32; ++e) {
+            const int j = (int)(s_key[T * 32 + e] & imask);
+            if (j >= P.hn) continue;
+            const float2 hv = s_h[j];
+            const float hxo = hv.x - ox, hyo = hv.y - oy;
+            if (!(fabsf(hxo) < BAND_FAR) || !(fabsf(hyo) < BAND_FAR)) bad = true;   // far, Inf or NaN: the tile is scored in full
+            mnx = fminf(mnx, hxo); mxx = fmaxf(mxx, hxo);
+            mny = fminf(mny, hyo); mxy = fmaxf(mxy, hyo);
+            ++nreal;
+        }
+        uint4 lo = make_uint4(0u, 0u, 0u, 0u), hi = make_uint4(0u, 0u, 0u, pk(0u, 0x3F80u));
+        float g = 0.f;
+        if (nreal > 0 && !bad) {
+            const float qx = 0.5f * (mnx + mxx), qy = 0.5f * (mny + mxy);   // centre, relative to the origin
+            float r2 = 0.f;
+            for (int e = 0; e < 32; ++e) {
+                const int j = (int)(s_key[T * 32 + e] & imask);
+                if (j >= P.hn) continue;
+                const float2 hv = s_h[j];
+                const float dx = (hv.x - ox) - qx, dy = (hv.y - oy) - qy;
+                r2 = fmaxf(r2, fmaf(dx, dx, dy * dy));
+            }
+            const float Rq = __builtin_sqrtf(fmaf(qx, qx, qy * qy)) * 1.000001f;
+            // radius of the disc about the point the column REALLY encodes (fl(q s) / s): the roundings of h - o, q, h - q, the
+            // square root and q s are relative 2^-24 each, of |h - o| <= Rq + rt at most
+            const float rt = __builtin_sqrtf(r2) * 1.000001f;
+            const float rtu = rt + 4.0e-7f * (Rq + rt);
+            const float G = rtu / P.thresh * 1.000001f;
+            const float E = P.kband * (Rq + rtu + rho);
+            const float S = G + E;
+            const float sc = bf16_floor(BAND_TARGET / S);
+            b_col_scaled(qx, qy, Rq + rtu, sc, lo, hi);
+            if (sc > 0.f && Rq + rtu < BAND_FAR) g = G / S * 0.99999f;   // (rounded down: the certainty threshold 1 - g (1 - mu) only grows)
+        }
+        uint4* o = P.hypc + (bk * ntl + T) * 2;
+        o[0] = lo;
+        o[1] = hi;
+        P.hypg[bk * ntl + T] = g;
     }
 }
 
@@ -1163,7 +1432,9 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
         }
         // the group's counts: atomic adds into counts[] (default), or one uint16 row per chunk GROUP for K5 to sum
         uint16_t* po = P.partial + (bk * P.max_chunks + cg) * P.hn_pad + h0;
-        if (MH >= 2 && P.atomic_counts) {  // tiles in pairs: lanes 0..31 finish tile t, lanes 32..63 tile t + 1
+        // (round 5, found by the knob fuzz: the pair form decodes the SUM of two lanes' wrapped accumulators -- up to 32 votes per
+        //  pixel tile, i.e. exactly 512 = 0 mod 512 when all 512 pixels of a 16-tile item vote (PVNET_SCORE_CHUNK=256): only below 16 tiles)
+        if (MH >= 2 && P.atomic_counts && ntiles < 16) {  // tiles in pairs: lanes 0..31 finish tile t, lanes 32..63 tile t + 1
 #pragma unroll
             for (int t = 0; t + 1 < MH; t += 2) {
                 const int c = votes_of(half_wave_sum2(cnt[t], cnt[t + 1]));
@@ -1428,7 +1699,8 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
             s_raw[i] = q;
             uint4* t = s_t + (i >> 5) * TILE_U4 + (i & 31) * 2;
             uint4 r0, r1, r2, r3;  // (in registers first: by reference into LDS every assignment inside would be a store)
-            a_rows_exact(q, P.tau, ox, oy, rho, r0, r1, r2, r3);
+            float mu_unused;
+            a_rows_exact(q, P.tau, ox, oy, rho, r0, r1, r2, r3, mu_unused);
             t[0] = r0;
             t[1] = r1;
             t[64] = r2;
@@ -1622,6 +1894,337 @@ PV_DEF_SCORE_EXACT4(8, 1, 1, 128) PV_DEF_SCORE_EXACT4(8, 2, 1, 160)
 #undef PV_DEF_SCORE_EXACT
 
 // ------------------------------------------------------------------------------------------------------------
+// K4 -- disc culling (round 5; exact mode, 8 hypothesis tiles per wave, 256-pixel work items): the exact kernel's two MFMAs and
+// 40 vector operations are only spent on the (pixel, hypothesis tile) pairs whose outcome geometry does not already fix.
+// Hypotheses arrive sorted along a Hilbert curve (hypothesis_cull_kernel): a tile of 32 is a disc (centre q, radius rho_T).
+//   coarse pass  per item, ONE MFMA pair per pixel tile against the 32 tile CENTRES of the item's hypothesis slice (the eight
+//                pixel tiles are shared out over the four waves): x' = s' |M_i| m_i(q).  |x'| >= 1 - g (1 - mu_i) means the
+//                pixel's margin has one sign on the whole disc, outside the rounding band for every hypothesis in it: the pixel
+//                votes for all 32 hypotheses (x' > 0: one count per tile, s_cv) or for none.  Every other pixel is UNCERTAIN
+//                for that tile and its A-row address joins the tile's list (s_list, 16-bit LDS row addresses).
+//   fine pass    a wave walks its eight hypothesis tiles; for each it scores ceil(uncertain / 32) GATHERED pixel groups -- lane
+//                `col` of the MFMA's A operand reads the row the list names, so any 32 pixels of the item form a tile -- with
+//                the exact kernel's epilogue (vote_subs / vote_slow_open / vote_slow_close: x = dt' - |cr'|, cells of 16 tests,
+//                flagged cells re-evaluated literally).  Lists are padded to whole groups with a dead row (x = -4).
+// Every count is the same integer as before: certain pixels add what the full test would have added (proof: DESIGN.md section 4),
+// uncertain ones run the very same arithmetic.  What changes is the work: on the noisy benchmark field 59 % of the steps remain
+// at thresh 0.99 (simulation: tools/cull_study.py, profiles/r05_cull_study.txt), none on a clean field.
+// ------------------------------------------------------------------------------------------------------------
+template <bool TIMED, bool RUNS>
+__device__ __forceinline__ void score_cull_body(VoteParams P) {
+    constexpr int MH = 8;
+    PVNET_SPARE_VGPRS(143);   // (136 usable: three waves per SIMD -- which the 48 KB of LDS per workgroup allow anyway)
+    unsigned long long* __restrict__ stamps = reinterpret_cast<unsigned long long*>(P.pix);
+    if (TIMED && threadIdx.x == 0) stamps[2 * blockIdx.x] = (unsigned long long)wall_clock64();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint4* s_t = reinterpret_cast<uint4*>(smem);                                  // 8 A tiles + the dead row's tile: 9 x 2 KB
+    float4* s_raw = reinterpret_cast<float4*>(s_t + 9 * TILE_U4);                 // raw records of the pixel group
+    unsigned* s_cells = reinterpret_cast<unsigned*>(s_raw + CULL_NPX);            // flagged cells of this item (4 * MH * 64 slots)
+    uint16_t* s_list = reinterpret_cast<uint16_t*>(s_cells + 4 * MH * 64);        // [32 tiles][256] A-row addresses of the uncertain pixels
+    float* s_sig = reinterpret_cast<float*>(s_list + 32 * CULL_NPX);              // [256] 1 - mu_i
+    int* s_nu = reinterpret_cast<int*>(s_sig + CULL_NPX);                         // [32] uncertain pixels per hypothesis tile
+    int* s_cv = s_nu + 32;                                                        // [32] certain votes per hypothesis tile
+    __shared__ int s_ncell;
+    const int32_t* __restrict__ ctrl = P.ctrl;
+    const int total = ctrl[P.b * CTRL_STRIDE];
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint4* lbase = s_t + col * 2 + half;
+    const int ntl = P.hn_pad >> 5;
+
+    unsigned long long ph[4] = {0ull, 0ull, 0ull, 0ull}, tprev = 0ull;
+#define PV_PHASE(i)                                                     \
+    do {                                                                \
+        if (TIMED) {                                                    \
+            const unsigned long long now_ = (unsigned long long)clock64(); \
+            ph[i] += now_ - tprev;                                      \
+            tprev = now_;                                               \
+        }                                                               \
+    } while (0)
+    if (TIMED) tprev = (unsigned long long)clock64();
+    bf16x8 B[MH];
+    bf16x8 Bc = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));   // centre column of hypothesis tile `col` of the slice
+    float gcol = 0.f;                                                     // its g (0: every live pixel is uncertain)
+    bool tile_live = false;                                               // tile `col` holds a real hypothesis
+    unsigned cnt[MH];   // packed-norm vote counters (votes_of_norm): fine votes of the clean cells + the certain votes
+#pragma unroll
+    for (int t = 0; t < MH; ++t) cnt[t] = 0u;
+    long long run_key = -1;
+    int run_h0 = 0, run_items = 0;
+    size_t run_bk = 0;
+    unsigned st_steps = 0u, st_full = 0u;   // PVNET_F_BAND_STATS: fine steps executed / steps the exact kernel would execute (this wave)
+    auto flush_counts = [&](size_t fbk, int fh0) {
+        int32_t* const pc = P.cnts + fbk * P.hn_pad + fh0;
+        int lanex = threadIdx.x;
+        asm volatile("" : "+v"(lanex));
+        lanex &= 63;
+#pragma unroll
+        for (int t = 0; t + 1 < MH; t += 2) {  // lanes 0..31 finish tile t, lanes 32..63 tile t + 1
+            const int c = votes_of_norm(half_wave_sum2(cnt[t], cnt[t + 1]));
+            if (c > 0) atomicAdd(pc + t * 32 + lanex, c);
+        }
+#pragma unroll
+        for (int t = 0; t < MH; ++t) cnt[t] = 0u;
+    };
+    const ItemRange ir = my_items<RUNS>(P, total);
+    for (int item = ir.first; item < ir.end; item += ir.step) {
+        const int4 desc = P.items[item];
+        const int bi = desc.x, k = desc.y, cg = desc.z, hq = desc.w;
+        const int tn = ctrl[bi * CTRL_STRIDE + C_TN];
+        const float rho = band_rho(tn);
+        const size_t bk = (size_t)bi * P.vn + k;
+        const int32_t* const org = band_origin_ptr(P, bk);
+        const float ox = (float)org[0], oy = (float)org[1];
+        const int tpad = (tn + PAD - 1) / PAD * PAD;
+        const int hslice = hq * 4 * MH * 32;
+        const int h0 = hslice + wave * MH * 32;
+        const long long key = (long long)bk * (P.hgroups / P.wg_g) + hq;
+        // a run's counters hold < 65536 votes per half: per item and lane pair at most 16 fine votes per group (8 groups) and the
+        // certain votes of the item's 256 pixels -- 384: a run is cut after 160 items
+        const bool fresh = !RUNS || key != run_key || run_items >= 160;
+
+        lds_barrier();  // the previous item's tiles, lists and cells have been consumed
+        PV_PHASE(3);
+        if (threadIdx.x == 0) s_ncell = 0;
+        if (threadIdx.x < 64) s_nu[threadIdx.x] = 0;   // s_nu and s_cv
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        if (fresh) {
+            if (RUNS && run_key >= 0) flush_counts(run_bk, run_h0);
+            run_key = key;
+            run_bk = bk;
+            run_h0 = h0;
+            run_items = 0;
+            const int c2 = tid & 31, h2 = (tid >> 5) & 1;
+#pragma unroll
+            for (int t = 0; t < MH; ++t) {
+                const uint4 raw = P.hypb[(bk * P.hn_pad + h0 + t * 32 + c2) * 2 + h2];
+                B[t] = __builtin_bit_cast(bf16x8, raw);
+            }
+            Bc = __builtin_bit_cast(bf16x8, P.hypc[(bk * ntl + hq * 32 + c2) * 2 + h2]);
+            gcol = P.hypg[bk * ntl + hq * 32 + c2];
+            tile_live = hslice + c2 * 32 < P.hn;
+        }
+        ++run_items;
+        {   // thread = pixel: its A rows, its raw record, its 1 - mu
+            const int i = tid;
+            const int p = cg * CULL_NPX + i;
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < tpad) q = P.rec[bk * P.cap + p];
+            s_raw[i] = q;
+            uint4* t = s_t + (i >> 5) * TILE_U4 + (i & 31) * 2;
+            uint4 r0, r1, r2, r3;
+            float mu;
+            a_rows_exact(q, P.tau, ox, oy, rho, r0, r1, r2, r3, mu);
+            t[0] = r0;
+            t[1] = r1;
+            t[64] = r2;
+            t[65] = r3;
+            s_sig[i] = 1.f - mu;
+            if (i == 0) {   // the dead row the lists are padded with: dt' = -4, cr' = 0 -- no vote, no flag
+                s_t[CULL_DEAD] = make_uint4(0u, 0u, 0u, 0u);
+                s_t[CULL_DEAD + 1] = make_uint4(0u, 0u, 0u, pk(0u, 0xC080u));
+                s_t[CULL_DEAD + 64] = make_uint4(0u, 0u, 0u, 0u);
+                s_t[CULL_DEAD + 65] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        lds_barrier();
+        PV_PHASE(0);
+
+        const int left = (tpad - cg * CULL_NPX + 31) >> 5;
+        const int nti = left < 8 ? left : 8;
+        // ---- coarse pass: this wave's two pixel tiles against the 32 tile centres
+        for (int pt = wave * 2; pt < wave * 2 + 2; ++pt) {
+            if (pt >= nti) break;   // wave-uniform
+            const bf16x8 Ad = __builtin_bit_cast(bf16x8, lbase[pt * TILE_U4]);
+            const bf16x8 Ac = __builtin_bit_cast(bf16x8, lbase[pt * TILE_U4 + 64]);
+            const f32x16 vd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ad, Bc, zero, 0, 0, 0);
+            const f32x16 vc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac, Bc, zero, 0, 0, 0);
+            unsigned um = 0u;
+            int nv = 0;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 sg = *reinterpret_cast<const float4*>(s_sig + pt * 32 + r4 * 8 + half * 4);   // rows r4 * 8 + half * 4 + 0..3
+                const float se[4] = {sg.x, sg.y, sg.z, sg.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = r4 * 4 + e;
+                    const float x = vd[r] - fabsf(vc[r]);
+                    const float thr = fmaf(-gcol, se[e], 1.f);   // 1 - g (1 - mu)
+                    const bool vote = x >= thr, none = x <= -thr;   // (NaN: neither -- uncertain)
+                    nv += vote ? 1 : 0;
+                    um |= (vote || none) ? 0u : (1u << r);
+                }
+            }
+            if (!tile_live) {   // a tile of padding hypotheses only: never scored, nobody reads its counts
+                um = 0u;
+                nv = 0;
+            }
+            if (nv) atomicAdd(&s_cv[col], nv);
+            if (um) {
+                int at = atomicAdd(&s_nu[col], __popc(um));
+                uint16_t* const dst = s_list + col * CULL_NPX;
+                while (um) {
+                    const int r = __ffs((int)um) - 1;
+                    um &= um - 1u;
+                    dst[at++] = (uint16_t)(pt * TILE_U4 + ((r >> 2) * 8 + half * 4 + (r & 3)) * 2);   // uint4 index of the pixel's dt' row
+                }
+            }
+        }
+        lds_barrier();
+        // ---- fine pass: the uncertain pixels of each of this wave's eight hypothesis tiles, gathered into groups of 32
+#pragma unroll
+        for (int t = 0; t < MH; ++t) {   // pad the wave's own lists to whole groups with the dead row (wave-local: LDS operations of a wave stay in order)
+            const int nu = s_nu[wave * MH + t];
+            if (lane < 32 && nu + lane < ((nu + 31) & ~31)) s_list[(wave * MH + t) * CULL_NPX + nu + lane] = (uint16_t)CULL_DEAD;
+        }
+        unsigned flg[MH];   // bit (groups - 1 - g) set = gathered group g of tile t holds a test inside the band
+        float x0, x1, x2, x3, x4, x5, x6, x7, dmo;
+        unsigned acc;
+#define PV_XS x0, x1, x2, x3, x4, x5, x6, x7
+#define PV_LO(v, w) v[0], w[0], v[1], w[1], v[2], w[2], v[3], w[3], v[4], w[4], v[5], w[5], v[6], w[6], v[7], w[7]
+#define PV_HI(v, w) v[8], w[8], v[9], w[9], v[10], w[10], v[11], w[11], v[12], w[12], v[13], w[13], v[14], w[14], v[15], w[15]
+#pragma unroll
+        for (int t = 0; t < MH; ++t) {
+            flg[t] = 0u;
+            const int j = wave * MH + t;
+            const int nu = __builtin_amdgcn_readfirstlane(s_nu[j]);
+            const int ng = (nu + 31) >> 5;
+            if (TIMED || (P.flags & PVNET_F_BAND_STATS)) {
+                st_steps += (unsigned)ng;
+                st_full += (h0 + t * 32 < P.hn) ? (unsigned)nti : 0u;
+            }
+            if (ng > 0) {   // wave-uniform
+                // Software pipeline over the tile's gathered groups: a group's A rows are requested one trip ahead (list entry -> row
+                // address -> two 16-byte reads: a dependent LDS chain of ~200 cycles that would otherwise open every step) and the
+                // previous group's last 15 vote operations fill the wait for this group's MFMAs, as in the exact kernel.
+                const uint16_t* const lst = s_list + j * CULL_NPX + col;
+                const unsigned a0 = lst[0];
+                uint4 Ra = s_t[a0 + half], Rb = s_t[a0 + half + 64];
+                unsigned an = lst[ng > 1 ? 32 : 0];
+                {
+                    const f32x16 va = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Ra), B[t], zero, 0, 0, 0);
+                    const f32x16 vb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Rb), B[t], zero, 0, 0, 0);
+                    Ra = s_t[an + half];
+                    Rb = s_t[an + half + 64];
+                    an = lst[(ng > 2 ? 2 : ng - 1) * 32];
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_nop 11");   // (the votes are inline asm: the wait states are ours, tools/check_mfma_hazard.py)
+                    vote_subs(PV_XS, PV_LO(va, vb));
+                    vote_slow_open(acc, dmo, PV_XS);
+                    vote_subs(PV_XS, PV_HI(va, vb));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                for (int g = 1; g < ng; ++g) {
+                    const f32x16 va = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Ra), B[t], zero, 0, 0, 0);
+                    const f32x16 vb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Rb), B[t], zero, 0, 0, 0);
+                    Ra = s_t[an + half];        // (the last trip re-reads the last group: harmless)
+                    Rb = s_t[an + half + 64];
+                    an = lst[(g + 2 < ng ? g + 2 : ng - 1) * 32];
+                    __builtin_amdgcn_sched_barrier(0);
+                    vote_slow_close(cnt[t], flg[t], acc, dmo, PV_XS);   // the previous group's last 15 operations fill the wait
+                    asm volatile("s_nop 3");
+                    vote_subs(PV_XS, PV_LO(va, vb));
+                    vote_slow_open(acc, dmo, PV_XS);
+                    vote_subs(PV_XS, PV_HI(va, vb));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                vote_slow_close(cnt[t], flg[t], acc, dmo, PV_XS);
+            }
+            // the tile's certain votes: the same for its 32 hypotheses; added in ONE of the two half-waves that half_wave_sum2 joins
+            const unsigned cv = (unsigned)s_cv[j];
+            cnt[t] += half == 0 ? cv * 0xFFFFu : 0u;
+        }
+#undef PV_XS
+#undef PV_LO
+#undef PV_HI
+        PV_PHASE(1);
+        int colx = col;
+        asm volatile("" : "+v"(colx));
+        const bool padded = h0 + MH * 32 > P.hn;
+        if (!RUNS) flush_counts(bk, h0);
+#pragma unroll
+        for (int t = 0; t < MH; ++t) {
+            unsigned mask = flg[t];
+            if (padded && h0 + t * 32 + colx >= P.hn) mask = 0u;   // padding columns: nobody reads their counts
+            const unsigned long long bal = __ballot(mask != 0u);
+            if (bal) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_ncell, __popcll(bal));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                if (mask != 0u) s_cells[slot] = (unsigned)(wave * MH * 32 + t * 32 + colx) | ((unsigned)half << 10) | (mask << 11);
+            }
+        }
+        lds_barrier();
+        PV_PHASE(2);
+        // ---- flagged cells, decided by the reference's arithmetic: 16 lanes per cell, one gathered pixel each
+        const int ncell = s_ncell;
+        if (ncell > 0) {
+            int tid2 = threadIdx.x;
+            asm volatile("" : "+v"(tid2));
+            const int grp = tid2 >> 4, q = tid2 & 15;
+            int ntests = 0;
+            for (int e = grp; e < ncell; e += 16) {
+                const unsigned cell = s_cells[e];
+                const int hl = (int)(cell & 1023u), hf = (int)((cell >> 10) & 1u);
+                unsigned m = cell >> 11;
+                const float2 hv = P.hyps[bk * P.hn_pad + hslice + hl];
+                const int j = hl >> 5;
+                const int nu = s_nu[j], ng = (nu + 31) >> 5;
+                const int row = (q >> 2) * 8 + hf * 4 + (q & 3);  // the 16 rows a lane of that half-wave holds
+                int votes = 0;
+                while (m) {
+                    const int gb = __ffs((int)m) - 1;   // bit gb = gathered group ng - 1 - gb (vote_slow_close shifts them in)
+                    m &= m - 1u;
+                    const int slot = (ng - 1 - gb) * 32 + row;
+                    if (slot < nu) {   // (beyond: the dead row)
+                        const unsigned a = s_list[j * CULL_NPX + slot];
+                        const float4 r = s_raw[(a >> 7) * 32 + ((a & 127u) >> 1)];
+                        votes += inlier_literal(r.x, r.y, r.z, r.w, hv.x, hv.y, P.thresh) ? 1 : 0;
+                        ++ntests;
+                    }
+                }
+                votes += __shfl_xor(votes, 8, 64);
+                votes += __shfl_xor(votes, 4, 64);
+                votes += __shfl_xor(votes, 2, 64);
+                votes += __shfl_xor(votes, 1, 64);
+                if (q == 0 && votes > 0) atomicAdd(P.cnts + bk * P.hn_pad + hslice + hl, votes);
+            }
+            if (P.flags & PVNET_F_BAND_STATS) {
+                if (tid2 == 0) atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 4, ncell);
+                if (q == 0 && ntests > 0) atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 5, ntests);
+            }
+        }
+    }
+    if (RUNS && run_key >= 0) flush_counts(run_bk, run_h0);
+    if ((P.flags & PVNET_F_BAND_STATS) && lane == 0) {   // development aid: how much of the exact kernel's work was left
+        atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 1, (int)st_steps);
+        atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 7, (int)st_full);
+    }
+    if (TIMED) {
+        lds_barrier();
+        PV_PHASE(3);
+        if (threadIdx.x == 0) {
+            stamps[2 * blockIdx.x + 1] = (unsigned long long)wall_clock64();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stamps[2 * gridDim.x + 4 * blockIdx.x + i] = ph[i];
+        }
+    }
+#undef PV_PHASE
+}
+#define PV_DEF_SCORE_CULL(TIMED_, RUNS_)                                                                                  \
+    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8), amdgpu_num_vgpr(68))) void                \
+        score_exact_kernel_cull_##TIMED_##_##RUNS_(VoteParams P) {                                                        \
+        score_cull_body<TIMED_ != 0, RUNS_ != 0>(P);                                                                      \
+    }
+PV_DEF_SCORE_CULL(0, 0) PV_DEF_SCORE_CULL(1, 0) PV_DEF_SCORE_CULL(0, 1) PV_DEF_SCORE_CULL(1, 1)
+#undef PV_DEF_SCORE_CULL
+constexpr size_t CULL_LDS_BYTES = 9 * TILE_U4 * sizeof(uint4) + CULL_NPX * sizeof(float4) + 4 * 8 * 64 * sizeof(unsigned) +
+                                  32 * CULL_NPX * sizeof(uint16_t) + CULL_NPX * sizeof(float) + 64 * sizeof(int);
+
+// ------------------------------------------------------------------------------------------------------------
 // Development aid (pvnet_vote_band_margin, tools/band_margin.py): the exactness argument of the exact mode, MEASURED.
 // On the workspace a complete exact-mode call left behind, every (pixel, hypothesis) test is evaluated twice: x = dt' - |cr'|
 // from the very MFMAs, operands and subtraction the scoring kernel uses (same instructions on the same bits: the same x), and
@@ -1651,7 +2254,8 @@ __global__ __launch_bounds__(256) void band_margin_kernel(VoteParams P, unsigned
         if (p < tpad) q = P.rec[bk * P.cap + p];
         s_raw[i] = q;
         uint4 r0, r1, r2, r3;
-        a_rows_exact(q, P.tau, ox, oy, rho, r0, r1, r2, r3);
+        float mu_unused;
+        a_rows_exact(q, P.tau, ox, oy, rho, r0, r1, r2, r3, mu_unused);
         uint4* t = s_t + (i >> 5) * TILE_U4 + (i & 31) * 2;
         t[0] = r0;
         t[1] = r1;
@@ -1664,10 +2268,10 @@ __global__ __launch_bounds__(256) void band_margin_kernel(VoteParams P, unsigned
     const int left = (tpad - grp * 256 + 31) >> 5, nti = left < 8 ? left : 8;
     float worst = 0.f;
     unsigned ndis = 0u, nband = 0u, ntest = 0u;
-    for (int ht = wave; ht * 32 < P.hn; ht += 4) {     // hypothesis tiles of this wave
+    for (int ht = wave; ht * 32 < (P.cull ? P.hn_pad : P.hn); ht += 4) {     // hypothesis tiles of this wave
         const int h = ht * 32 + col;
         const bf16x8 Bc = __builtin_bit_cast(bf16x8, P.hypb[(bk * P.hn_pad + h) * 2 + half]);
-        const float2 hv = P.hyp[bk * P.hn_pad + h];
+        const float2 hv = (P.cull ? P.hyps : P.hyp)[bk * P.hn_pad + h];   // (disc culling: hypb is in Hilbert order, and so is hyps)
         for (int tile = 0; tile < nti; ++tile) {
             const bf16x8 Ad = __builtin_bit_cast(bf16x8, lbase[tile * TILE_U4]);
             const bf16x8 Ac = __builtin_bit_cast(bf16x8, lbase[tile * TILE_U4 + 64]);
@@ -1677,7 +2281,7 @@ __global__ __launch_bounds__(256) void band_margin_kernel(VoteParams P, unsigned
             for (int r = 0; r < 16; ++r) {
                 const int row = (r >> 2) * 8 + half * 4 + (r & 3);
                 const int p = grp * 256 + tile * 32 + row;
-                if (p >= tn || h >= P.hn) continue;    // padding rows / columns: nobody reads their counts
+                if (p >= tn || (P.cull ? P.perm[bk * P.hn_pad + h] >= P.hn : h >= P.hn)) continue;    // padding rows / columns: nobody reads their counts
                 const float x = vd[r] - fabsf(vc[r]);  // (one IEEE subtraction, as v_sub_f32 x, d, |c|)
                 const float4 q = s_raw[tile * 32 + row];
                 const bool lit = inlier_literal(q.x, q.y, q.z, q.w, hv.x, hv.y, P.thresh);
@@ -1757,7 +2361,17 @@ __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
     // (one 32-bit load per chunk row) with eight loads in flight: the rows are latency-, not bandwidth-bound.
     unsigned long long best = 0;
     const size_t row = (size_t)(P.hn_pad >> 1);  // hn_pad is even
-    if (P.atomic_counts) {  // K4 already summed: one value per hypothesis
+    if (!LITERAL && P.cull) {  // disc culling: K4 counted in Hilbert order -- back to the caller's order (what every reader of
+                               // `counts` expects), the first CALLER index winning ties as before
+        for (int p = threadIdx.x; p < P.hn_pad; p += RT) {
+            const int h = P.perm[bk * P.hn_pad + p];
+            if (h >= P.hn) continue;   // padding
+            const uint32_t c = (uint32_t)P.cnts[bk * P.hn_pad + p];
+            P.counts[bk * P.hn_pad + h] = (int32_t)c;
+            const unsigned long long key = ((unsigned long long)c << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)h);
+            best = key > best ? key : best;
+        }
+    } else if (P.atomic_counts) {  // K4 already summed: one value per hypothesis
         for (int h = threadIdx.x; h < P.hn; h += RT) {
             const uint32_t c = (uint32_t)P.counts[bk * P.hn_pad + h];
             const unsigned long long key = ((unsigned long long)c << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)h);
@@ -2193,7 +2807,7 @@ int layout_fingerprint(const PvnetVoteLayout& L) {
     uint64_t x = 0x9E3779B97F4A7C15ull;
     const uint64_t v[] = {(uint64_t)L.chunk, (uint64_t)L.hpl, (uint64_t)L.wg_g, (uint64_t)L.reserved_, (uint64_t)L.cap,
                           (uint64_t)L.hn_pad, (uint64_t)L.off_rec, (uint64_t)L.off_hyp, (uint64_t)L.off_counts,
-                          (uint64_t)L.off_win, (uint64_t)L.total_bytes};
+                          (uint64_t)L.off_win, (uint64_t)L.total_bytes, (uint64_t)L.cull, (uint64_t)L.off_perm};
     for (uint64_t e : v) { x ^= e + 0x9E3779B97F4A7C15ull + (x << 6) + (x >> 2); }
     const int fp = (int)(x ^ (x >> 32));
     return fp ? fp : 1;
@@ -2227,6 +2841,10 @@ struct Tuning {
     int score_runs;     // PVNET_SCORE_RUNS        exact mode, 8 tiles per wave: 1 = contiguous item runs per workgroup (B columns, hypotheses and
                         //                         vote counters kept while the (image, key-point) stays), 0 = strided items;
                         //                         -1 (default): runs for calls flagged PVNET_F_CONCURRENT
+    int score_cull;     // PVNET_SCORE_CULL        exact mode, 8 tiles per wave, 256-pixel items, hn_pad <= 4096: 1 = disc culling
+                        //                         (hypotheses sorted along a Hilbert curve, per-pixel certainty against every tile's
+                        //                         disc, uncertain pixels gathered: score_exact_kernel_cull), 0 = the full kernel;
+                        //                         -1 (default): PVNET_CULL_DEFAULT
     int exact_fold;     // PVNET_EXACT_FOLD        exact mode: -1 (default) = by threshold, 0 = one cell per work item and
                         //                         hypothesis, 1 = one cell per pixel tile (band_fold1())
     int dev_stages;     // PVNET_DEV_STAGES        development aid: bit mask of the stages to launch
@@ -2244,6 +2862,7 @@ void load_tuning(Tuning& t) {
     t.score_acc = env_int("PVNET_SCORE_ACC", -1);
     t.exact_fold = env_int("PVNET_EXACT_FOLD", -1);
     t.score_runs = env_int("PVNET_SCORE_RUNS", -1);
+    t.score_cull = env_int("PVNET_SCORE_CULL", -1);
     t.dev_stages = env_int("PVNET_DEV_STAGES", 0x3F);
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -2333,7 +2952,12 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
     PV_HIP(mark(3));
     if (stages & 8) {   // K3
         dim3 grid((unsigned)(((P.hn * P.vn + 255) / 256 + 1) * ((P.b + 7) / 8) * 8));
-        if (literal) hipLaunchKernelGGL(hypothesis_kernel<true>, grid, dim3(256), 0, s, P);
+        if (P.cull) {   // one workgroup per (image, key-point): hypotheses, Hilbert sort, tile discs (+ one plan block per image)
+            int n2 = 1;
+            while (n2 < P.hn_pad) n2 <<= 1;
+            const size_t lds = (size_t)P.hn_pad * sizeof(float2) + (size_t)n2 * sizeof(uint32_t);
+            hipLaunchKernelGGL(hypothesis_cull_kernel, dim3((unsigned)((P.vn + 1) * ((P.b + 7) / 8) * 8)), dim3(256), lds, s, P);
+        } else if (literal) hipLaunchKernelGGL(hypothesis_kernel<true>, grid, dim3(256), 0, s, P);
         else hipLaunchKernelGGL(hypothesis_kernel<false>, grid, dim3(256), 0, s, P);
         PV_LAUNCH_CHECK();
     }
@@ -2348,7 +2972,22 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
         if (wgs > max_items) wgs = max_items;
         if (wgs < 1) wgs = 1;
         if (score_grid) *score_grid = (int)wgs;
-        if (P.exact) {
+        if (P.cull) {
+            const bool conc = (P.flags & PVNET_F_CONCURRENT) != 0;
+            const bool runs = T.score_runs == 1 || (T.score_runs < 0 && conc);
+            long long w2 = T.wgs_per_cu >= 0 ? wgs : (long long)T.cus * 9;   // three resident workgroups per CU (48 KB of LDS each): three rounds
+            if (w2 > max_items) w2 = max_items;
+            if (w2 < 1) w2 = 1;
+            if (score_grid) *score_grid = (int)w2;
+            const dim3 g((unsigned)w2), t(256);
+            if (timed_score) {
+                if (runs) hipLaunchKernelGGL(score_exact_kernel_cull_1_1, g, t, CULL_LDS_BYTES, s, P);
+                else hipLaunchKernelGGL(score_exact_kernel_cull_1_0, g, t, CULL_LDS_BYTES, s, P);
+            } else {
+                if (runs) hipLaunchKernelGGL(score_exact_kernel_cull_0_1, g, t, CULL_LDS_BYTES, s, P);
+                else hipLaunchKernelGGL(score_exact_kernel_cull_0_0, g, t, CULL_LDS_BYTES, s, P);
+            }
+        } else if (P.exact) {
             const int mh = P.wg_g * P.hpl / 2;
             const int npx = P.wg_s * P.chunk;
             size_t lds = (size_t)(npx / 32) * TILE_U4 * sizeof(uint4) + (size_t)npx * sizeof(float4) +
@@ -2488,6 +3127,13 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     P.counts = reinterpret_cast<int32_t*>(base + L.off_counts);
     P.win = reinterpret_cast<int32_t*>(base + L.off_win);
     P.out = out; P.status = status;
+    // disc culling: the layout has its buffers, the call runs the exact mode with cells of one pixel tile
+    P.cull = (L.cull && P.exact && P.fold1) ? 1 : 0;
+    P.perm = reinterpret_cast<int32_t*>(base + L.off_perm);
+    P.hyps = reinterpret_cast<float2*>(base + L.off_hyps);
+    P.cnts = reinterpret_cast<int32_t*>(base + L.off_cnts);
+    P.hypc = reinterpret_cast<uint4*>(base + L.off_hypc);
+    P.hypg = reinterpret_cast<float*>(base + L.off_hypc + align_up(sizeof(uint4) * 2 * (size_t)b * vn * (L.hn_pad / 32), 256));
     return 0;
 }
 
@@ -2564,6 +3210,14 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     L->off_partial = take(T.score_atomic ? 0 : sizeof(uint16_t) * (size_t)b * vn * L->max_chunks * L->hn_pad);
     L->off_counts = take(sizeof(int32_t) * (size_t)b * vn * L->hn_pad);
     L->off_win = take(sizeof(int32_t) * 2 * (size_t)b * vn);
+    // disc culling (exact mode): 8 hypothesis tiles per wave, 256-pixel work items, a key-point's hypotheses sortable in LDS
+    const int cull_knob = T.score_cull >= 0 ? T.score_cull : PVNET_CULL_DEFAULT;
+    L->cull = (cull_knob && mode && T.score_atomic && wg_g * hpl / 2 == 8 && L->wg_s * chunk == CULL_NPX && L->hn_pad <= CULL_MAX_HN) ? 1 : 0;
+    L->off_perm = take(L->cull ? sizeof(int32_t) * (size_t)b * vn * L->hn_pad : 0);
+    L->off_hyps = take(L->cull ? sizeof(float) * 2 * (size_t)b * vn * L->hn_pad : 0);
+    L->off_cnts = take(L->cull ? sizeof(int32_t) * (size_t)b * vn * L->hn_pad : 0);
+    // tile centres uint4 [b][vn][hn_pad / 32][2], then their g float [b][vn][hn_pad / 32]
+    L->off_hypc = take(L->cull ? (sizeof(uint4) * 2 + sizeof(float)) * (size_t)b * vn * (L->hn_pad / 32) + 256 : 0);
     L->total_bytes = off;
     return 0;
 }

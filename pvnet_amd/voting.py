@@ -42,7 +42,8 @@ class Layout(C.Structure):
                [(n, C.c_size_t) for n in ("off_ctrl", "off_bits", "off_pix", "off_rec", "off_hyp",
                                           "off_partial", "off_counts", "off_win", "off_seg", "off_items", "off_hypb",
                                           "total_bytes")] + \
-               [("nseg", C.c_int32), ("wg_g", C.c_int32), ("wg_s", C.c_int32), ("reserved_", C.c_int32)]
+               [("nseg", C.c_int32), ("wg_g", C.c_int32), ("wg_s", C.c_int32), ("reserved_", C.c_int32), ("cull", C.c_int32)] + \
+               [(n, C.c_size_t) for n in ("off_perm", "off_hyps", "off_cnts", "off_hypc")]
 
 
 _lib = None
@@ -101,7 +102,7 @@ def load_library() -> C.CDLL:
     lib.pvnet_vote_band_margin.argtypes = [C.c_float, C.c_void_p] + ws_tail
     lib.pvnet_vote_tuning_reload.restype = None
     lib.pvnet_vote_tuning_reload.argtypes = []
-    if lib.pvnet_vote_abi_version() != 7:
+    if lib.pvnet_vote_abi_version() != 8:
         raise RuntimeError("pvnet_amd: libpvnet_vote.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib
@@ -336,8 +337,11 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
         # what the library really ran: without the matrix-pipe buffers (PVNET_SCORE_MODE=0) the default mode is scored literally
         d["mode"] = "literal" if (literal or (not approx and not L.reserved_)) else ("approx" if approx else "exact")
         d["concurrent"] = bool(flags & F_CONCURRENT)
+        d["cull"] = bool(L.cull) and d["mode"] == "exact"   # (and cells of one pixel tile: PVNET_EXACT_FOLD != 0)
         if band_stats:  # (cells re-evaluated, literal tests made) of this call; synchronises
             d["band_stats"] = tuple(int(x) for x in d["ctrl"][b, 4:6].tolist())
+            # disc culling: (fine steps executed, steps the full exact kernel would have executed); (0, 0) when the call did not cull
+            d["cull_stats"] = (int(d["ctrl"][b, 1]), int(d["ctrl"][b, 7]))
         d["status"] = status
         d["seed"] = seed
         d["workspace"] = ws

@@ -28,7 +28,7 @@ def test_exports_every_declared_symbol(lib):
             "pvnet_voting_for_hypothesis_vanishing_point", "pvnet_vote_build_info"} <= names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/pvnet_vote.h but not exported"
-    assert lib.pvnet_vote_abi_version() == 7
+    assert lib.pvnet_vote_abi_version() == 8
     assert b"gfx950" in lib.pvnet_vote_build_info()
 
 
