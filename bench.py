@@ -546,8 +546,9 @@ def main(argv=None):
     # calls on one stream are ordered, so they share it; nothing is allocated inside the timed regions
     G = max(1, a.gather_bucket if a.gather_bucket > 0 else nstreams)
     NBLK = 4  # staging / target blocks in rotation
+    GATHER_ON_VOTE = os.environ.get("BENCH_GATHER_ON_VOTING_STREAM") == "1"
     if dist is not None:
-        comm = torch.cuda.Stream(dev)
+        comm = None if GATHER_ON_VOTE else torch.cuda.Stream(dev)
         staging = [torch.empty((G, BATCH, VN, 2), dtype=torch.float32, device=dev) for _ in range(NBLK)]
         gathered = [torch.empty((world, G, BATCH, VN, 2), dtype=torch.float32, device=dev) for _ in range(NBLK)]
         sent = [None] * NBLK  # event: the gather that last read staging[blk] is done
@@ -561,16 +562,20 @@ def main(argv=None):
             return
         # one event per STREAM that voted into the bucket, recorded now (it covers every vote the stream was given), instead
         # of one per step: the communication stream is the only one that waits across streams
-        evs = [streams[si].record_event() for si in sorted(bucket["used"])]
-        with torch.cuda.stream(comm):
+        used = sorted(bucket["used"])
+        # BENCH_GATHER_ON_VOTING_STREAM=1 (experiment): no separate communication stream -- the collective is
+        # issued from the voting stream that filled the bucket's last slot, after it has waited for the other streams' votes
+        tgt = streams[used[-1]] if GATHER_ON_VOTE else comm
+        evs = [streams[si].record_event() for si in used if streams[si] is not tgt]
+        with torch.cuda.stream(tgt):
             for ev in evs:
-                comm.wait_event(ev)
+                tgt.wait_event(ev)
             # a last, partly filled bucket is sent whole (its unused slots carry the previous contents): no allocation and
             # no copy inside the timed region, one collective of the same size as every other
             w = dist.all_gather_into_tensor(gathered[blk], staging[blk], async_op=True)
             w.wait()  # comm stream waits for the collective
             sent[blk] = torch.cuda.Event()
-            sent[blk].record(comm)
+            sent[blk].record(tgt)
         pending.append(sent[blk])
         del pending[:-NBLK]  # (older gathers are ordered before these on the communication stream)
         bucket["n"] += 1
@@ -773,6 +778,7 @@ def main(argv=None):
                                      "VALU (5 calls on one stream)"},
             "per_rank_votings_per_s": per_rank, "gather_ms": gather_ms,
             "gather_bucket_steps": G if dist is not None else None,
+            "gather_stream": ("a voting stream (BENCH_GATHER_ON_VOTING_STREAM=1)" if GATHER_ON_VOTE else "its own stream") if dist is not None else None,
             "rccl_ranks_seen": len(seen) if seen else None,
             "rank_devices": [{"rank": r, "local_rank": l, "device": d} for r, l, d in seen] if seen else None,
             "dtype": "f32 decisions (bf16x3 MFMA products, f32 accumulate; pairs inside the f32 rounding band re-evaluated "

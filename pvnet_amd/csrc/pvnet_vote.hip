@@ -723,15 +723,18 @@ __device__ __forceinline__ int plan_item_count(const VoteParams& P, int j, int* 
     return ((nch + P.wg_s - 1) / P.wg_s) * P.vn * (P.hgroups / P.wg_g);
 }
 
+template <int NT = 256>   // threads of the calling workgroup
 __device__ __forceinline__ void plan_image(const VoteParams& P, int bi) {
-    __shared__ int s_part[4];
+    __shared__ int s_part[NT / 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int part = 0;
-    for (int j = threadIdx.x; j < bi; j += 256) part += plan_item_count(P, j, nullptr);
+    for (int j = threadIdx.x; j < bi; j += NT) part += plan_item_count(P, j, nullptr);
     part = wave_reduce_add(part);
     if (lane == 0) s_part[wave] = part;
     __syncthreads();
-    const int base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) base += s_part[i];
     int nch;
     const int n = plan_item_count(P, bi, &nch);
     if (threadIdx.x == 0) {
@@ -752,7 +755,7 @@ __device__ __forceinline__ void plan_image(const VoteParams& P, int bi) {
         }
     }
     const int HQ = P.hgroups / P.wg_g, nchg = (nch + P.wg_s - 1) / P.wg_s;
-    for (int local = threadIdx.x; local < n; local += 256) {
+    for (int local = threadIdx.x; local < n; local += NT) {
         const int hq = local % HQ, t = local / HQ;
         P.items[base + local] = make_int4(bi, t / nchg, t % nchg, hq);  // (image, key-point, chunk group, hyp slice)
     }
@@ -947,10 +950,12 @@ __device__ __forceinline__ uint32_t hilbert_index(uint32_t x, uint32_t y, int bi
     return d;
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(28))) void hypothesis_cull_kernel(VoteParams P) {
+constexpr int CULL_K3_THREADS = 1024;   // one hypothesis per thread at 1 024 hypotheses (up to four at 4 096)
+__global__ __launch_bounds__(CULL_K3_THREADS) void hypothesis_cull_kernel(VoteParams P) {
     PVNET_SPARE_VGPRS(63);
     small_stage_prio();
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = CULL_K3_THREADS, EMAX = CULL_MAX_HN / NT;
     // blocks of image bi on XCD bi % 8 (its records pass through one L2, as in hypothesis_kernel); vn + 1 blocks per image, the last plans
     const int nb = P.vn + 1;
     const int slot = blockIdx.x >> 3;
@@ -958,7 +963,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(28))) void hypo
     const int k = slot % nb;
     if (bi >= P.b) return;
     if (k == P.vn) {
-        plan_image(P, bi);
+        plan_image<NT>(P, bi);
         return;
     }
     const int tid = threadIdx.x;
@@ -966,9 +971,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(28))) void hypo
     const bool live = P.ctrl[bi * CTRL_STRIDE + C_TN0] >= P.min_num && tn > 0;  // gates of :531-534
     const size_t bk = (size_t)bi * P.vn + k;
     float2* s_h = reinterpret_cast<float2*>(smem);                  // [hn_pad] hypotheses, caller order
-    uint32_t* s_key = reinterpret_cast<uint32_t*>(s_h + P.hn_pad);  // [n2] (Hilbert position << idxbits) | caller index
-    int n2 = 1;
-    while (n2 < P.hn_pad) n2 <<= 1;
+    uint32_t* s_key = reinterpret_cast<uint32_t*>(s_h + P.hn_pad);  // [n2] exchange buffer of the sort's cross-wave stages
+    int n2 = NT;
+    while (n2 < P.hn_pad) n2 <<= 1;           // 1 024, 2 048 or 4 096 sort slots: E = n2 / 1 024 per thread, slot = e * 1 024 + tid
+    const int E = n2 / NT;
     const int idxbits = 31 - __clz(n2);
     const int cbits = (32 - idxbits) >> 1;   // bits per coordinate of the key: 11 at 1 024 hypotheses (+-128 px in 1/8 px), 10 at 4 096
     constexpr int NCAND = 8;
@@ -995,9 +1001,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(28))) void hypo
         s_cand[tid * 2] = cx;
         s_cand[tid * 2 + 1] = cy;
     }
-    // ---- this key-point's hypotheses (kernel.cu:11-49), caller order: thread t takes h = t, t + 256, ...
-    for (int h = tid; h < P.hn_pad; h += 256) {
-        float hx = 0.f, hy = 0.f;
+    // ---- this key-point's hypotheses (kernel.cu:11-49), caller order: thread t takes h = t, t + 1 024, ...; the record loads of
+    //      all of a thread's hypotheses are issued before the first intersection
+    float4 qa[EMAX], qb[EMAX];
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        const int h = e * NT + tid;
+        qa[e] = qb[e] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live && h < P.hn) {
             const int i = h * P.vn + k;   // the draw's index in the reference's [hn, vn, 2] layout
             int t0, t1;
@@ -1011,11 +1021,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(28))) void hypo
                 t0 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u), (uint32_t)tn);
                 t1 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u + 1u), (uint32_t)tn);
             }
-            const float4 q0 = P.rec[bk * P.cap + t0], q1 = P.rec[bk * P.cap + t1];
-            hyp_intersect(q0.z, q0.w, q0.x, q0.y, q1.z, q1.w, q1.x, q1.y, hx, hy);
+            qa[e] = P.rec[bk * P.cap + t0];
+            qb[e] = P.rec[bk * P.cap + t1];
         }
-        s_h[h] = make_float2(hx, hy);
-        if (h < P.hn) P.hyp[bk * P.hn_pad + h] = make_float2(hx, hy);
+    }
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        const int h = e * NT + tid;
+        if (h < P.hn_pad) {
+            float hx = 0.f, hy = 0.f;
+            if (live && h < P.hn) hyp_intersect(qa[e].z, qa[e].w, qa[e].x, qa[e].y, qb[e].z, qb[e].w, qb[e].x, qb[e].y, hx, hy);
+            s_h[h] = make_float2(hx, hy);
+            if (h < P.hn) P.hyp[bk * P.hn_pad + h] = make_float2(hx, hy);
+        }
     }
     __syncthreads();
     {   // median by rank, as in hypothesis_kernel (one key-point here)
@@ -1063,98 +1081,115 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(28))) void hypo
         o[1] = s_org[1];
     }
     // ---- sort keys: position on a Hilbert curve of 1/8-pixel cells about the origin; far and non-finite hypotheses clamp to the border
+    uint32_t key[EMAX];
     {
         const float cells = (float)(1 << cbits);
-        for (int h = tid; h < n2; h += 256) {
-            uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const int h = e * NT + tid;
+            uint32_t kv = 0xFFFFFFFFu;   // (slots beyond hn_pad, and the registers beyond E: behind everything)
             if (h < P.hn) {
                 const float2 hv = s_h[h];
                 const float fx = fminf(fmaxf((hv.x - ox) * 8.f + 0.5f * cells, 0.f), cells - 1.f);   // (NaN -> 0)
                 const float fy = fminf(fmaxf((hv.y - oy) * 8.f + 0.5f * cells, 0.f), cells - 1.f);
-                key = (hilbert_index((uint32_t)fx, (uint32_t)fy, cbits) << idxbits) | (uint32_t)h;
+                kv = (hilbert_index((uint32_t)fx, (uint32_t)fy, cbits) << idxbits) | (uint32_t)h;
             } else if (h < P.hn_pad) {
-                key = (0xFFFFFFFFu << idxbits) | (uint32_t)h;   // padding: behind every real hypothesis (ties broken by the index)
+                kv = (0xFFFFFFFFu << idxbits) | (uint32_t)h;   // padding: behind every real hypothesis (ties broken by the index)
             }
-            s_key[h] = key;
+            key[e] = kv;
         }
     }
-    __syncthreads();
-    for (int kk = 2; kk <= n2; kk <<= 1)   // bitonic sort, ascending
+    // ---- bitonic sort, ascending, slot i = e * 1 024 + tid: partners 1 .. 32 lanes away by shuffle, 64 .. 512 threads away through
+    //      LDS (two barriers), 1 024 / 2 048 slots away in the thread's own registers
+    auto cas = [&](uint32_t& mine_, uint32_t other, int i, int kk, int jj) {
+        const bool keep_min = ((i & jj) == 0) == ((i & kk) == 0);
+        const uint32_t lo = mine_ < other ? mine_ : other, hi = mine_ < other ? other : mine_;
+        mine_ = keep_min ? lo : hi;
+    };
+    for (int kk = 2; kk <= n2; kk <<= 1)
         for (int jj = kk >> 1; jj > 0; jj >>= 1) {
-            for (int i = tid; i < n2; i += 256) {
-                const int ixj = i ^ jj;
-                if (ixj > i) {
-                    const uint32_t a = s_key[i], c = s_key[ixj];
-                    const bool up = (i & kk) == 0;
-                    if ((a > c) == up) { s_key[i] = c; s_key[ixj] = a; }
+            if (jj >= NT) {   // (block-uniform)
+                if (jj == NT) {
+                    { const uint32_t a = key[0], c = key[1]; cas(key[0], c, tid, kk, jj); cas(key[1], a, NT + tid, kk, jj); }
+                    if (E > 2) { const uint32_t a = key[2], c = key[3]; cas(key[2], c, 2 * NT + tid, kk, jj); cas(key[3], a, 3 * NT + tid, kk, jj); }
+                } else {
+                    { const uint32_t a = key[0], c = key[2]; cas(key[0], c, tid, kk, jj); cas(key[2], a, 2 * NT + tid, kk, jj); }
+                    { const uint32_t a = key[1], c = key[3]; cas(key[1], c, NT + tid, kk, jj); cas(key[3], a, 3 * NT + tid, kk, jj); }
                 }
+            } else if (jj >= 64) {
+#pragma unroll
+                for (int e = 0; e < EMAX; ++e)
+                    if (e < E) s_key[e * NT + tid] = key[e];
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < EMAX; ++e)
+                    if (e < E) cas(key[e], s_key[(e * NT + tid) ^ jj], e * NT + tid, kk, jj);
+                __syncthreads();
+            } else {
+#pragma unroll
+                for (int e = 0; e < EMAX; ++e)
+                    if (e < E) cas(key[e], (uint32_t)__shfl_xor((int)key[e], jj, 64), e * NT + tid, kk, jj);
             }
-            __syncthreads();
         }
-    // ---- sorted outputs
+    // ---- sorted outputs + one disc per tile of 32 sorted hypotheses: a tile = the 32 lanes of a half-wave (slot p = e * 1 024 + tid)
     const uint32_t imask = (uint32_t)n2 - 1u;
-    for (int p = tid; p < P.hn_pad; p += 256) {
-        const int j = (int)(s_key[p] & imask);
+    const int ntl = P.hn_pad >> 5;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        const int p = e * NT + tid;
+        if (p >= P.hn_pad) continue;   // (uniform per half-wave: hn_pad is a multiple of 32)
+        const int j = (int)(key[e] & imask);
         const bool real = j < P.hn;
         const float2 hv = real ? s_h[j] : make_float2(0.f, 0.f);
         P.perm[bk * P.hn_pad + p] = j;
         P.hyps[bk * P.hn_pad + p] = hv;
         P.cnts[bk * P.hn_pad + p] = 0;   // K4 accumulates into it
-        uint4 lo, hi;
-        if (real) {
-            b_col_exact(hv.x - ox, hv.y - oy, rho, P.kband, lo, hi);
-        } else {
-            lo = make_uint4(0u, 0u, 0u, 0u);
-            hi = make_uint4(0u, 0u, 0u, pk(0u, 0x3F80u));
-        }
+        const float hxo = hv.x - ox, hyo = hv.y - oy;
+        uint4 lo = make_uint4(0u, 0u, 0u, 0u), hi = make_uint4(0u, 0u, 0u, pk(0u, 0x3F80u));
+        if (real) b_col_exact(hxo, hyo, rho, P.kband, lo, hi);
         uint4* o = P.hypb + (bk * P.hn_pad + p) * 2;
         o[0] = lo;
         o[1] = hi;
-    }
-    // ---- one disc per tile of 32 sorted hypotheses
-    const int ntl = P.hn_pad >> 5;
-    for (int T = tid; T < ntl; T += 256) {
-        float mnx = 3.0e38f, mny = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f;
-        bool bad = false;
-        int nreal = 0;
-        for (int e = 0; e < 32; ++e) {
-            const int j = (int)(s_key[T * 32 + e] & imask);
-            if (j >= P.hn) continue;
-            const float2 hv = s_h[j];
-            const float hxo = hv.x - ox, hyo = hv.y - oy;
-            if (!(fabsf(hxo) < BAND_FAR) || !(fabsf(hyo) < BAND_FAR)) bad = true;   // far, Inf or NaN: the tile is scored in full
-            mnx = fminf(mnx, hxo); mxx = fmaxf(mxx, hxo);
-            mny = fminf(mny, hyo); mxy = fmaxf(mxy, hyo);
-            ++nreal;
+        // the tile's bounding box, whether it holds a far / non-finite hypothesis, how many real ones: over the 32 lanes
+        float mnx = real ? hxo : 3.0e38f, mxx = real ? hxo : -3.0e38f, mny = real ? hyo : 3.0e38f, mxy = real ? hyo : -3.0e38f;
+        int bad = (real && (!(fabsf(hxo) < BAND_FAR) || !(fabsf(hyo) < BAND_FAR))) ? 1 : 0;   // far, Inf or NaN: the tile is scored in full
+        int nreal = real ? 1 : 0;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+            mnx = fminf(mnx, __shfl_xor(mnx, off, 64));
+            mxx = fmaxf(mxx, __shfl_xor(mxx, off, 64));
+            mny = fminf(mny, __shfl_xor(mny, off, 64));
+            mxy = fmaxf(mxy, __shfl_xor(mxy, off, 64));
+            bad |= __shfl_xor(bad, off, 64);
+            nreal += __shfl_xor(nreal, off, 64);
         }
-        uint4 lo = make_uint4(0u, 0u, 0u, 0u), hi = make_uint4(0u, 0u, 0u, pk(0u, 0x3F80u));
-        float g = 0.f;
-        if (nreal > 0 && !bad) {
-            const float qx = 0.5f * (mnx + mxx), qy = 0.5f * (mny + mxy);   // centre, relative to the origin
-            float r2 = 0.f;
-            for (int e = 0; e < 32; ++e) {
-                const int j = (int)(s_key[T * 32 + e] & imask);
-                if (j >= P.hn) continue;
-                const float2 hv = s_h[j];
-                const float dx = (hv.x - ox) - qx, dy = (hv.y - oy) - qy;
-                r2 = fmaxf(r2, fmaf(dx, dx, dy * dy));
+        const float qx = 0.5f * (mnx + mxx), qy = 0.5f * (mny + mxy);   // centre, relative to the origin
+        const float dx = hxo - qx, dy = hyo - qy;
+        float r2 = (real && !bad) ? fmaf(dx, dx, dy * dy) : 0.f;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, off, 64));
+        if ((tid & 31) == 0) {
+            uint4 clo = make_uint4(0u, 0u, 0u, 0u), chi = make_uint4(0u, 0u, 0u, pk(0u, 0x3F80u));
+            float g = 0.f;
+            if (nreal > 0 && !bad) {
+                const float Rq = __builtin_sqrtf(fmaf(qx, qx, qy * qy)) * 1.000001f;
+                // radius of the disc about the point the column REALLY encodes (fl(q s) / s): the roundings of h - o, q, h - q, the
+                // square root and q s are relative 2^-24 each, of |h - o| <= Rq + rt at most
+                const float rt = __builtin_sqrtf(r2) * 1.000001f;
+                const float rtu = rt + 4.0e-7f * (Rq + rt);
+                const float G = rtu / P.thresh * 1.000001f;
+                const float Eb = P.kband * (Rq + rtu + rho);
+                const float S = G + Eb;
+                const float sc = bf16_floor(BAND_TARGET / S);
+                b_col_scaled(qx, qy, Rq + rtu, sc, clo, chi);
+                if (sc > 0.f && Rq + rtu < BAND_FAR) g = G / S * 0.99999f;   // (rounded down: the certainty threshold 1 - g (1 - mu) only grows)
             }
-            const float Rq = __builtin_sqrtf(fmaf(qx, qx, qy * qy)) * 1.000001f;
-            // radius of the disc about the point the column REALLY encodes (fl(q s) / s): the roundings of h - o, q, h - q, the
-            // square root and q s are relative 2^-24 each, of |h - o| <= Rq + rt at most
-            const float rt = __builtin_sqrtf(r2) * 1.000001f;
-            const float rtu = rt + 4.0e-7f * (Rq + rt);
-            const float G = rtu / P.thresh * 1.000001f;
-            const float E = P.kband * (Rq + rtu + rho);
-            const float S = G + E;
-            const float sc = bf16_floor(BAND_TARGET / S);
-            b_col_scaled(qx, qy, Rq + rtu, sc, lo, hi);
-            if (sc > 0.f && Rq + rtu < BAND_FAR) g = G / S * 0.99999f;   // (rounded down: the certainty threshold 1 - g (1 - mu) only grows)
+            const int T = p >> 5;
+            uint4* oc = P.hypc + (bk * ntl + T) * 2;
+            oc[0] = clo;
+            oc[1] = chi;
+            P.hypg[bk * ntl + T] = g;
         }
-        uint4* o = P.hypc + (bk * ntl + T) * 2;
-        o[0] = lo;
-        o[1] = hi;
-        P.hypg[bk * ntl + T] = g;
     }
 }
 
@@ -2953,10 +2988,10 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
     if (stages & 8) {   // K3
         dim3 grid((unsigned)(((P.hn * P.vn + 255) / 256 + 1) * ((P.b + 7) / 8) * 8));
         if (P.cull) {   // one workgroup per (image, key-point): hypotheses, Hilbert sort, tile discs (+ one plan block per image)
-            int n2 = 1;
+            int n2 = CULL_K3_THREADS;
             while (n2 < P.hn_pad) n2 <<= 1;
             const size_t lds = (size_t)P.hn_pad * sizeof(float2) + (size_t)n2 * sizeof(uint32_t);
-            hipLaunchKernelGGL(hypothesis_cull_kernel, dim3((unsigned)((P.vn + 1) * ((P.b + 7) / 8) * 8)), dim3(256), lds, s, P);
+            hipLaunchKernelGGL(hypothesis_cull_kernel, dim3((unsigned)((P.vn + 1) * ((P.b + 7) / 8) * 8)), dim3(CULL_K3_THREADS), lds, s, P);
         } else if (literal) hipLaunchKernelGGL(hypothesis_kernel<true>, grid, dim3(256), 0, s, P);
         else hipLaunchKernelGGL(hypothesis_kernel<false>, grid, dim3(256), 0, s, P);
         PV_LAUNCH_CHECK();

@@ -1,0 +1,170 @@
+"""GPU tests of the exact mode's DISC CULLING (round 5; PVNET_SCORE_CULL=1, pvnet_vote.hip: hypothesis_cull_kernel /
+score_exact_kernel_cull): each key-point's hypotheses are sorted along a Hilbert curve, every tile of 32 is described by a disc,
+and a pixel whose margin at the disc's centre exceeds the disc's radius (+ the rounding band) votes for all 32 hypotheses of the
+tile or for none -- only the other pixels are gathered into MFMA tiles.  The claim under test: EVERY inlier count, every winner
+and every key-point is the one the full exact kernel (and therefore literal mode, i.e. the reference's own arithmetic:
+ransac_voting_kernel.cu:88-126) returns -- `torch.equal`, no tolerance -- while the work really shrinks."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import refkernels
+from pvnet_amd import synth, voting
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def batch(n, first, h, w, radius, noise=True, background="normal", **kw):
+    mask, planar, kpts = synth.make_batch(n, first_index=first, h=h, w=w, radius=radius, noise=noise, background=background, **kw)
+    m = torch.from_numpy(mask).to(dev())
+    v = synth.planar_to_vertex_view(torch.from_numpy(planar).to(dev()))
+    return m, v, kpts
+
+
+@pytest.fixture
+def cull(monkeypatch):
+    """the culling layout for the calls of one test; the library default comes back afterwards"""
+    def on(flag=True):
+        monkeypatch.setenv("PVNET_SCORE_CULL", "1" if flag else "0")
+        voting.reload_tuning()
+    yield on
+    monkeypatch.delenv("PVNET_SCORE_CULL", raising=False)
+    voting.reload_tuning()
+
+
+def snapshot(out, d):
+    return out.clone(), d["counts"].clone(), d["win"].clone(), d["hyp"].clone()
+
+
+@pytest.mark.parametrize("thresh", [0.9, 0.99, 0.999])
+@pytest.mark.parametrize("conc", [False, True])
+def test_culled_counts_equal_literal_and_full_kernel_at_the_bench_shape(cull, thresh, conc):
+    m, v, _ = batch(4, 40, 480, 640, 40)
+    lit = snapshot(*voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=thresh, seed=3, literal=True, return_debug=True))
+    cull(False)
+    full = snapshot(*voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=thresh, seed=3, return_debug=True, concurrent=conc))
+    cull(True)
+    out, d = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=thresh, seed=3, return_debug=True, concurrent=conc,
+                                           band_stats=True)
+    assert d["cull"] and d["layout"].cull == 1 and d["mode"] == "exact"
+    assert d["hyp"].cpu().numpy().tobytes() == lit[3].cpu().numpy().tobytes()   # caller order, the same draws
+    assert torch.equal(d["counts"], lit[1]) and torch.equal(d["counts"], full[1])
+    assert torch.equal(d["win"], lit[2]) and torch.equal(d["win"], full[2])
+    assert torch.equal(out, full[0])                       # same inlier sets, same float64 sums: bit-identical key-points
+    ex, total = d["cull_stats"]
+    assert 0 < ex < total                                   # and part of the full kernel's steps was really not executed
+    if thresh == 0.9:
+        assert ex < 0.6 * total
+
+
+@pytest.mark.skipif(not refkernels.available("off"), reason="oracle/_ref (the reference's kernels compiled for gfx950) not built")
+def test_culled_counts_equal_the_references_own_kernel(cull):
+    """the reference's voting_for_hypothesis_kernel itself (oracle/_ref) on the path's compacted pixels and hypotheses"""
+    m, v, _ = batch(2, 60, 480, 640, 40)
+    cull(True)
+    _, d = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=11, return_debug=True)
+    assert d["cull"]
+    for bi in range(2):
+        tn = int(d["tn"][bi])
+        rec = d["rec"][bi, :, :tn]
+        coords = rec[0, :, 0:2].contiguous()
+        direct = rec[:, :, 2:4].permute(1, 0, 2).contiguous()
+        hyp = d["hyp"][bi].permute(1, 0, 2).contiguous()
+        inl = refkernels.voting_for_hypothesis(direct, coords, hyp, 0.99)
+        assert torch.equal(d["counts"][bi].T, inl.sum(2, dtype=torch.int32))
+
+
+def test_clean_field_is_almost_entirely_certain(cull):
+    """every hypothesis of a clean field is the key-point itself: tiles of radius ~0, (nearly) every pixel certain -- the fine
+    pass has next to nothing left, and the winner still collects every pixel"""
+    m, v, kpts = batch(3, 70, 480, 640, 40, noise=False, background="zeros")
+    cull(True)
+    out, d = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=2, return_debug=True, band_stats=True)
+    ex, total = d["cull_stats"]
+    assert d["cull"] and ex < 0.05 * total
+    assert (d["win"][:, :, 1] == d["tn"][:3, None]).all()
+    assert np.abs(out.cpu().numpy() - kpts).max() < 1e-3
+    lit_out, dl = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=2, literal=True, return_debug=True)
+    assert torch.equal(d["counts"], dl["counts"])
+
+
+@pytest.mark.parametrize("hn,b", [(777, 3), (1024, 1), (2048, 2), (1500, 2), (4096, 1)])
+def test_padding_hypotheses_several_slices_and_the_sort_limit(cull, hn, b):
+    """hn = 777 / 1500: padding columns inside the last tile and whole padding tiles; 2048 / 4096: two / four hypothesis slices
+    per key-point, each with its own 32 tile centres; 4096 is the largest count the sort handles (beyond: the full kernel)"""
+    m, v, _ = batch(b, 80 + hn, 240, 320, 30)
+    lit = snapshot(*voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=0.99, seed=5, literal=True, return_debug=True))
+    cull(True)
+    out, d = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=0.99, seed=5, return_debug=True)
+    assert d["cull"]
+    assert torch.equal(d["counts"], lit[1]) and torch.equal(d["win"], lit[2])
+    assert d["hyp"].cpu().numpy().tobytes() == lit[3].cpu().numpy().tobytes()
+    assert float((out - lit[0]).abs().max()) < 1e-3
+
+
+def test_layouts_the_culling_kernel_does_not_cover_run_the_full_kernel(cull):
+    cull(True)
+    m, v, _ = batch(2, 90, 240, 320, 24)
+    for hn in (256, 8192):   # 2 hypothesis tiles per wave / more hypotheses than the sort holds in LDS
+        _, lit = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=0.99, seed=6, literal=True, return_debug=True)
+        cl = lit["counts"].clone()
+        _, d = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=0.99, seed=6, return_debug=True)
+        assert not d["cull"] and d["mode"] == "exact" and torch.equal(d["counts"], cl)
+
+
+def test_unnormalised_dead_and_far_inputs(cull):
+    """|u| scaled per pixel over many orders of magnitude, zero / sub-gate / NaN / Inf directions (dead rows: certain non-votes),
+    near-parallel fields whose hypotheses lie 1e6 px away (tiles with huge discs: everything uncertain, scored in full)"""
+    rng = np.random.default_rng(17)
+    mask, planar, _ = synth.make_batch(2, first_index=95, h=240, w=320, radius=30, noise=True, background="normal")
+    fac = np.exp(rng.normal(0.0, 3.0, size=(2, 1, 240, 320))).astype(np.float32)
+    fac[rng.random(fac.shape) < 0.02] = 0.0
+    fac[rng.random(fac.shape) < 0.02] = 1e-7
+    planar = (planar.reshape(2, 9, 2, 240, 320) * fac[:, :, None]).reshape(2, 18, 240, 320).astype(np.float32)
+    ys, xs = np.nonzero(mask[0])
+    planar[0, 0, ys[::11], xs[::11]] = np.nan
+    planar[0, 3, ys[::13], xs[::13]] = np.inf
+    m = torch.from_numpy(mask).to(dev())
+    v = synth.planar_to_vertex_view(torch.from_numpy(planar).to(dev()))
+    _, lit = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=8, literal=True, return_debug=True)
+    cl, wl = lit["counts"].clone(), lit["win"].clone()
+    cull(True)
+    _, d = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=8, return_debug=True)
+    assert d["cull"] and torch.equal(d["counts"], cl) and torch.equal(d["win"], wl)
+    # far key-points: all directions of a key-point nearly parallel
+    h, w = 96, 128
+    yy, xx = np.mgrid[0:h, 0:w]
+    fg = ((xx - 64) ** 2 + (yy - 48) ** 2) <= 20 ** 2
+    far = synth.field_from_keypoints(fg, np.array([[2.0e6, 48.0], [-3.0e8, 1.0e8]]))
+    m2 = torch.from_numpy(fg[None].astype(np.uint8)).to(dev())
+    v2 = synth.planar_to_vertex_view(torch.from_numpy(far[None].astype(np.float32)).to(dev()))
+    cull(False)
+    _, lit2 = voting.ransac_voting_layer_v3(m2, v2, 1024, inlier_thresh=0.99, seed=9, literal=True, return_debug=True)
+    c2 = lit2["counts"].clone()
+    cull(True)
+    _, d2 = voting.ransac_voting_layer_v3(m2, v2, 1024, inlier_thresh=0.99, seed=9, return_debug=True)
+    assert d2["cull"] and torch.equal(d2["counts"], c2)
+
+
+def test_siblings_read_caller_order_counts_and_the_band_margin_still_holds(cull):
+    """the sibling epilogues (distribution, hypothesis counts) read `counts` / `hyp` in CALLER order -- K5 returns the culled
+    counts to it -- and the measured safety margin of the rounding band is evaluated on the sorted operands"""
+    m, v, _ = batch(2, 99, 240, 320, 30)
+    cull(False)
+    hyp0, cnt0 = voting.generate_hypothesis_counts(m, v, 1024, inlier_thresh=0.99, seed=4)
+    mean = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=4)
+    _, cov0 = voting.estimate_voting_distribution_with_mean(m, v, mean, round_hyp_num=256, min_hyp_num=1024, seed=4)
+    cov0 = cov0.clone()
+    cull(True)
+    hyp1, cnt1 = voting.generate_hypothesis_counts(m, v, 1024, inlier_thresh=0.99, seed=4)
+    assert torch.equal(hyp0, hyp1) and torch.equal(cnt0, cnt1)
+    _, cov1 = voting.estimate_voting_distribution_with_mean(m, v, mean, round_hyp_num=256, min_hyp_num=1024, seed=4)
+    assert torch.equal(cov0, cov1)
+    _, d = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=4, return_debug=True)
+    bm = voting.band_margin(d, 0.99)
+    assert bm["tests"] > 1e7 and bm["worst"] < 0.5
