@@ -3209,6 +3209,9 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
 
     const long long units = (long long)b * vn * hgroups;
     int chunk = units >= 128 ? 128 : 64;
+    // disc culling works on 256-pixel items (two chunks of 128): where it applies, small batches keep that shape too
+    const int cull_knob = T.score_cull >= 0 ? T.score_cull : PVNET_CULL_DEFAULT;
+    if (cull_knob && mode && T.score_atomic && wg_g * hpl / 2 == 8 && hgroups * 64 * hpl <= CULL_MAX_HN) chunk = CULL_NPX / (4 / wg_g);
     if (T.chunk >= 0) chunk = T.chunk;
     if (chunk < PAD || chunk % PAD != 0 || chunk > 1024) return PVNET_E_UNSUPPORTED;  // LDS: 4 * 1024 * 32 B
     if (mode && chunk % 32 != 0) return PVNET_E_UNSUPPORTED;  // whole 32-pixel MFMA tiles
@@ -3246,7 +3249,6 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     L->off_counts = take(sizeof(int32_t) * (size_t)b * vn * L->hn_pad);
     L->off_win = take(sizeof(int32_t) * 2 * (size_t)b * vn);
     // disc culling (exact mode): 8 hypothesis tiles per wave, 256-pixel work items, a key-point's hypotheses sortable in LDS
-    const int cull_knob = T.score_cull >= 0 ? T.score_cull : PVNET_CULL_DEFAULT;
     L->cull = (cull_knob && mode && T.score_atomic && wg_g * hpl / 2 == 8 && L->wg_s * chunk == CULL_NPX && L->hn_pad <= CULL_MAX_HN) ? 1 : 0;
     L->off_perm = take(L->cull ? sizeof(int32_t) * (size_t)b * vn * L->hn_pad : 0);
     L->off_hyps = take(L->cull ? sizeof(float) * 2 * (size_t)b * vn * L->hn_pad : 0);
