@@ -1888,10 +1888,7 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
                 votes += __shfl_xor(votes, 1, 64);
                 if (q == 0 && votes > 0) atomicAdd(P.counts + bk * P.hn_pad + hslice + hl, votes);
             }
-            if (P.flags & PVNET_F_BAND_STATS) {
-                ntests = wave_reduce_add(ntests);
-                if (lane == 0 && ntests > 0) atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 5, ntests);
-            }
+            if ((P.flags & PVNET_F_BAND_STATS) && q == 0 && ntests > 0) atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 5, ntests);
         }
     }
     if (RUNS && run_key >= 0) flush_counts(run_bk, run_h0);
@@ -2396,21 +2393,15 @@ __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
     // kernel only lists them, CELL_CAP per (work item, wave)).  The quarters' fill counts are scanned RT at a time; 16 lanes take one
     // cell -- one pixel row each, as the scoring kernel's own re-evaluation did -- and add its literal votes to the hypothesis' count.
     if (!LITERAL && P.exact && !P.cull) {
-        // Two phases per chunk of ECH cells, so that no lane ever waits for a chain of dependent global loads: (A) every thread fetches
-        // and decodes cells into LDS (hypothesis index, half-wave, first pixel of the work item, tile mask / tile count); (B) groups
-        // of FOUR lanes take one (cell, pixel tile) unit each -- a lane tests four consecutive records (64 contiguous bytes) -- 128
-        // units in flight per workgroup, one global round trip each.
-        constexpr int ECH = 2 * RT;
         __shared__ int s_excl[RT + 1];
         __shared__ int s_wtot[RW];
-        __shared__ uint32_t s_ch[ECH], s_cp[ECH], s_cm[ECH];   // per cell: hypothesis | half << 31; first pixel of its item; tile mask | nti << 24
         const int HQ = P.hgroups / P.wg_g, nchg = (nchunks + P.wg_s - 1) / P.wg_s;
         const size_t quarter0 = ((size_t)P.ctrl[bi * CTRL_STRIDE + C_ITEM_BASE] + (size_t)k * nchg * HQ) * 4;   // K3 planned the items in (key-point, pixel group, slice) order
         const int nquarters = nchg * HQ * 4;
         const int mh = P.wg_g * P.hpl / 2, npx = P.wg_s * P.chunk, ntiles = npx >> 5;
         const int tn_ = P.ctrl[bi * CTRL_STRIDE + C_TN];
         const int tpad = (tn_ + PAD - 1) / PAD * PAD;
-        const int per = P.fold1 ? 1 : ntiles;   // units per cell: its flagged tiles (nearly always one) / every tile of the item
+        const int grp = threadIdx.x >> 4, q = threadIdx.x & 15;
         int ntests = 0;
         for (int base = 0; base < nquarters; base += RT) {
             const int qi = base + (int)threadIdx.x;
@@ -2432,55 +2423,43 @@ __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
             s_excl[threadIdx.x] = off + incl - c;
             if (threadIdx.x == 0) s_excl[RT] = total;
             __syncthreads();
-            for (int e0 = 0; e0 < total; e0 += ECH) {
-                const int nch_ = total - e0 < ECH ? total - e0 : ECH;
-                for (int i = threadIdx.x; i < nch_; i += RT) {   // (A)
-                    const int e = e0 + i;
-                    int lo = 0;   // the quarter holding entry e: the last one whose exclusive prefix is <= e
+            for (int e = grp; e < total; e += RT / 16) {
+                int lo = 0;   // the quarter holding entry e: the last one whose exclusive prefix is <= e
 #pragma unroll
-                    for (int st = RT / 2; st > 0; st >>= 1) lo += (s_excl[lo + st] <= e) ? st : 0;
-                    const int quarter = base + lo, slot = e - s_excl[lo];
-                    const unsigned cell = P.cells[(quarter0 + quarter) * CELL_CAP + slot];
-                    const int rel = quarter >> 2, cg = rel / HQ, hq = rel - cg * HQ;
-                    const int p0 = cg * npx;
-                    const int left = (tpad - p0 + 31) >> 5, nti = left < ntiles ? left : ntiles;
-                    s_ch[i] = (uint32_t)(hq * 4 * mh * 32 + (int)(cell & 1023u)) | ((cell >> 10) & 1u) << 31;
-                    s_cp[i] = (uint32_t)p0;
-                    s_cm[i] = (cell >> 11) | ((uint32_t)nti << 24);
-                }
-                __syncthreads();
-                const int sub = threadIdx.x & 3;
-                for (int u = (int)(threadIdx.x >> 2); u < nch_ * per; u += RT / 4) {   // (B)
-                    const int i = P.fold1 ? u : u / ntiles;
-                    const uint32_t ch = s_ch[i], cm = s_cm[i];
-                    const int hidx = (int)(ch & 0x7FFFFFFFu), hf = (int)(ch >> 31), p0 = (int)s_cp[i], nti = (int)(cm >> 24);
-                    const float2 hv = P.hyp[bk * P.hn_pad + hidx];
-                    unsigned m = P.fold1 ? (cm & 0xFFFFFFu) : 1u;
-                    int votes = 0;
-                    while (m) {   // cells of one pixel tile: bit g = pixel tile nti - 1 - g (vote_slow_close shifts them in)
-                        const int g = __ffs((int)m) - 1;
-                        m &= m - 1u;
-                        const int tile = P.fold1 ? nti - 1 - g : u - i * ntiles;
-                        if (tile >= nti) continue;   // (cells of a whole item: the item's last tiles may be empty)
-                        const int p = p0 + tile * 32 + sub * 8 + hf * 4;   // this lane's four rows: (q >> 2) * 8 + hf * 4 + (q & 3), q = 4 sub ..
-                        float4 r[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) r[j] = p + j < tpad ? P.rec[bk * P.cap + p + j] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) votes += inlier_literal(r[j].x, r[j].y, r[j].z, r[j].w, hv.x, hv.y, P.thresh) ? 1 : 0;
-                        ntests += 4;
+                for (int st = RT / 2; st > 0; st >>= 1) lo += (s_excl[lo + st] <= e) ? st : 0;
+                const int quarter = base + lo, slot = e - s_excl[lo];
+                const unsigned cell = P.cells[(quarter0 + quarter) * CELL_CAP + slot];
+                const int rel = quarter >> 2, cg = rel / HQ, hq = rel - cg * HQ;
+                const int hl = (int)(cell & 1023u), hf = (int)((cell >> 10) & 1u);
+                unsigned m = cell >> 11;
+                const int hidx = hq * 4 * mh * 32 + hl;
+                const float2 hv = P.hyp[bk * P.hn_pad + hidx];
+                const int p0 = cg * npx;
+                const int left = (tpad - p0 + 31) >> 5, nti = left < ntiles ? left : ntiles;
+                const int row = (q >> 2) * 8 + hf * 4 + (q & 3);  // the 16 rows a lane of that half-wave holds
+                int votes = 0;
+                while (m) {
+                    const int g = __ffs((int)m) - 1;  // cells of one pixel tile: bit g = pixel tile nti - 1 - g (vote_slow_close shifts them in)
+                    m &= m - 1u;
+                    const int t0 = P.fold1 ? nti - 1 - g : 0, t1 = P.fold1 ? t0 + 1 : nti;
+                    for (int tile = t0; tile < t1; ++tile) {
+                        const int p = p0 + tile * 32 + row;
+                        if (p < tpad) {   // (records up to tpad exist: sentinels past tn never vote)
+                            const float4 r = P.rec[bk * P.cap + p];
+                            votes += inlier_literal(r.x, r.y, r.z, r.w, hv.x, hv.y, P.thresh) ? 1 : 0;
+                        }
+                        ++ntests;
                     }
-                    votes += __shfl_xor(votes, 2, 64);
-                    votes += __shfl_xor(votes, 1, 64);
-                    if (sub == 0 && votes > 0) atomicAdd(P.counts + bk * P.hn_pad + hidx, votes);
                 }
-                __syncthreads();   // s_ch / s_cp / s_cm are rewritten by the next chunk
+                votes += __shfl_xor(votes, 8, 64);
+                votes += __shfl_xor(votes, 4, 64);
+                votes += __shfl_xor(votes, 2, 64);
+                votes += __shfl_xor(votes, 1, 64);
+                if (q == 0 && votes > 0) atomicAdd(P.counts + bk * P.hn_pad + hidx, votes);
             }
+            __syncthreads();   // s_excl / s_wtot are rewritten by the next round
         }
-        if (P.flags & PVNET_F_BAND_STATS) {   // (pixel, hypothesis) tests made with the reference's arithmetic
-            ntests = wave_reduce_add(ntests);
-            if (lane == 0 && ntests > 0) atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 5, ntests);
-        }
+        if ((P.flags & PVNET_F_BAND_STATS) && q == 0 && ntests > 0) atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 5, ntests);
         __threadfence();   // the counts this workgroup has just completed are read below by its other threads
         __syncthreads();
     }
