@@ -130,9 +130,6 @@ typedef struct PvnetVoteLayout {
     size_t off_hyps;        /* float2 [b][vn][hn_pad]      hypotheses in sorted order                                          */
     size_t off_cnts;        /* int32  [b][vn][hn_pad]      inlier counts in sorted order (`counts` holds them in CALLER order)  */
     size_t off_hypc;        /* uint4  [b][vn][hn_pad/32][2] B column of every tile's centre, then float [b][vn][hn_pad/32] g    */
-    size_t off_cells;       /* exact mode (ABI 8): uint32 [max items][4][64] cells of the scoring kernel's work items that hold a test
-                               inside the rounding band (hypothesis in the item | half-wave << 10 | pixel-tile mask << 11), then
-                               int32 [max items][4] their number; select_refine re-evaluates them in the reference's operation order */
 } PvnetVoteLayout;
 
 /* Host-only: fills *out for a problem size.  max_num as passed to pvnet_vote_v3. */

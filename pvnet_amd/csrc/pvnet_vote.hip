@@ -102,8 +102,6 @@ constexpr int K2_WORDS_PER_BLOCK = SEG_WORDS;
 constexpr int THIN_BINS = (PVNET_THIN_LAST + 1 + 127) / 128 * 128;   // 1536: histogram length, an EVEN number of bins per lane
 constexpr int PAD = 8;                 // scoring consumes records 8 at a time; tails are padded with sentinels
 constexpr int TILE_U4_ = 128;          // uint4 per 32-pixel A tile of the matrix-pipe kernels (= TILE_U4 below)
-constexpr int CELL_CAP = 64;           // flagged cells a wave can hand to K5 per work item (4 on average at thresh 0.99, 24 at 0.999);
-                                       // what does not fit is re-evaluated by the wave itself, at once
 
 struct VoteParams {
     const void* mask;
@@ -139,10 +137,6 @@ struct VoteParams {
     int32_t* win;
     float* out;
     int32_t* status;
-    // deferred re-evaluation (round 5): the exact kernel lists its flagged cells per (work item, wave) instead of re-evaluating them
-    // behind a third barrier; select_refine_kernel re-evaluates the list of its (image, key-point) before it takes the arg-max
-    uint32_t* cells;     // [max items][4 waves][CELL_CAP] flagged cells: hypothesis index in the item | half-wave << 10 | tile mask << 11
-    int32_t* cellcnt;    // [max items][4] entries of each quarter (written by every (item, wave): nothing to zero)
     // disc culling (round 5; section "K4 -- disc culling" below): hypotheses sorted along a Hilbert curve per key-point
     int cull;            // 1: this call scores with score_exact_kernel_cull (exact mode, 8 tiles per wave, 256-pixel items)
     int32_t* perm;       // [b][vn][hn_pad] sorted position -> caller's hypothesis index
@@ -1647,7 +1641,9 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
     const int npx = P.wg_s * P.chunk, ntiles = npx >> 5;
     uint4* s_t = reinterpret_cast<uint4*>(smem);                        // A tiles: ntiles x 2 KB  (A_a rows | A_b rows)
     float4* s_raw = reinterpret_cast<float4*>(s_t + ntiles * TILE_U4);  // raw records of the pixel group
-    unsigned* s_cells = reinterpret_cast<unsigned*>(s_raw + npx);       // per wave MH * 64 slots: flagged cells beyond CELL_CAP (rare)
+    float2* s_hyp = reinterpret_cast<float2*>(s_raw + npx);             // the item's 4 * MH * 32 hypotheses (for the flagged cells)
+    unsigned* s_cells = reinterpret_cast<unsigned*>(s_hyp + 4 * MH * 32);  // flagged cells of this item (4 * MH * 64 slots)
+    __shared__ int s_ncell;
     const int32_t* __restrict__ ctrl = P.ctrl;
     const int total = ctrl[P.b * CTRL_STRIDE];
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1711,14 +1707,19 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
 
         lds_barrier();  // the previous item's tiles, raw records and cell list have been consumed
         PV_PHASE(3);
+        if (threadIdx.x == 0) s_ncell = 0;
         int tid = threadIdx.x;  // opaque copies of the thread index: what staging and re-evaluation derive from it is
         asm volatile("" : "+v"(tid));  // recomputed per item instead of staying in VGPRs across the scoring loop
+        float2 hreg[(4 * MH * 32 + 255) / 256];  // the run's hypotheses: loaded now, parked in LDS after the staging arithmetic
         if (fresh) {
             if (RUNS && run_key >= 0) flush_counts(run_bk, run_h0);
             run_key = key;
             run_bk = bk;
             run_h0 = h0;
             run_items = 0;
+#pragma unroll
+            for (int j = 0; j < (4 * MH * 32 + 255) / 256; ++j)
+                hreg[j] = (tid + 256 * j < 4 * MH * 32) ? P.hyp[bk * P.hn_pad + hslice + tid + 256 * j] : make_float2(0.f, 0.f);
 #pragma unroll
             for (int t = 0; t < MH; ++t) {
                 const uint4 raw = P.hypb[(bk * P.hn_pad + h0 + t * 32 + (tid & 31)) * 2 + ((tid >> 5) & 1)];  // (column, half-wave)
@@ -1739,6 +1740,11 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
             t[1] = r1;
             t[64] = r2;
             t[65] = r3;
+        }
+        if (fresh) {
+#pragma unroll
+            for (int j = 0; j < (4 * MH * 32 + 255) / 256; ++j)
+                if (tid + 256 * j < 4 * MH * 32) s_hyp[tid + 256 * j] = hreg[j];
         }
         lds_barrier();
         PV_PHASE(0);
@@ -1837,43 +1843,37 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
             for (int t = 0; t < MH; ++t) cnt[t] = dmn[t] >= BAND_CLEAN ? cnt[t] : 0u;  // a flagged cell's votes are discarded
         }
         if (!RUNS) flush_counts(bk, h0);  // (RUNS: when the run ends)
-        // Flagged cells go to this (item, wave)'s quarter of the global cell list: select_refine_kernel re-evaluates them with the
-        // reference's arithmetic before it takes the arg-max (round 5 -- until round 4 the whole workgroup did it here, behind a
-        // third barrier: 13-14 % of the kernel at thresh 0.99, 31 % at 0.999, most lanes idle).  A quarter holds CELL_CAP cells;
-        // what does not fit (rare) is listed in LDS and decided by this wave itself, at once -- no barrier either way.
-        uint32_t* const creg = P.cells + ((size_t)item * 4 + wave) * CELL_CAP;
-        unsigned* const over = s_cells + wave * MH * 64;
-        int wcount = 0;   // wave-uniform
 #pragma unroll
         for (int t = 0; t < MH; ++t) {
             unsigned mask = FOLD ? flg[t] : (dmn[t] >= BAND_CLEAN ? 0u : all_groups);
             if (padded && h0 + t * 32 + colx >= P.hn) mask = 0u;  // padding columns of the last slice: nobody reads their counts
             const unsigned long long bal = __ballot(mask != 0u);
             if (bal) {  // wave-uniform
-                const int slot = wcount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                if (mask != 0u) {
-                    const unsigned entry = (unsigned)(wave * MH * 32 + t * 32 + colx) | ((unsigned)half << 10) | (mask << 11);
-                    if (slot < CELL_CAP) creg[slot] = entry;
-                    else over[slot - CELL_CAP] = entry;
-                }
-                wcount += (int)__popcll(bal);
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_ncell, __popcll(bal));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                if (mask != 0u) s_cells[slot] = (unsigned)(wave * MH * 32 + t * 32 + colx) | ((unsigned)half << 10) | (mask << 11);
             }
         }
-        if (lane == 0) P.cellcnt[(size_t)item * 4 + wave] = wcount < CELL_CAP ? wcount : CELL_CAP;   // (every call rewrites it: nothing to zero)
+        lds_barrier();
         PV_PHASE(2);
-        if ((P.flags & PVNET_F_BAND_STATS) && lane == 0 && wcount > 0) atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 4, wcount);
-        if (wcount > CELL_CAP) {   // wave-uniform, rare: the cells beyond the quarter, 16 lanes per cell, four cells at a time
-            const int grp = lane >> 4, q = lane & 15;
+        // ---- flagged cells, decided by the reference's arithmetic: 16 lanes per cell, one pixel row each
+        const int ncell = s_ncell;
+        if (ncell > 0) {
+            int tid2 = threadIdx.x;
+            asm volatile("" : "+v"(tid2));
+            const int grp = tid2 >> 4, q = tid2 & 15;
             int ntests = 0;
-            for (int e = grp; e < wcount - CELL_CAP; e += 4) {
-                const unsigned cell = over[e];
+            for (int e = grp; e < ncell; e += 16) {
+                const unsigned cell = s_cells[e];
                 const int hl = (int)(cell & 1023u), hf = (int)((cell >> 10) & 1u);
                 unsigned m = cell >> 11;
-                const float2 hv = P.hyp[bk * P.hn_pad + hslice + hl];
+                const float2 hv = s_hyp[hl];
                 const int row = (q >> 2) * 8 + hf * 4 + (q & 3);  // the 16 rows a lane of that half-wave holds
                 int votes = 0;
                 while (m) {
-                    const int g = __ffs((int)m) - 1;  // FOLD: bit g = pixel tile nti - 1 - g (vote_slow_close shifts them in)
+                    const int g = __ffs((int)m) - 1;  // FOLD: bit g = pixel tile nti - 1 - g (vote8x_close shifts them in)
                     m &= m - 1u;
                     const int t0 = FOLD ? nti - 1 - g : 0, t1 = FOLD ? t0 + 1 : nti;
                     for (int tile = t0; tile < t1; ++tile) {
@@ -1888,7 +1888,10 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
                 votes += __shfl_xor(votes, 1, 64);
                 if (q == 0 && votes > 0) atomicAdd(P.counts + bk * P.hn_pad + hslice + hl, votes);
             }
-            if ((P.flags & PVNET_F_BAND_STATS) && q == 0 && ntests > 0) atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 5, ntests);
+            if (P.flags & PVNET_F_BAND_STATS) {  // development aid: how much was re-evaluated (tools/exact_probe.py)
+                if (tid2 == 0) atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 4, ncell);
+                if (q == 0 && ntests > 0) atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 5, ntests);
+            }
         }
     }
     if (RUNS && run_key >= 0) flush_counts(run_bk, run_h0);
@@ -2389,80 +2392,6 @@ __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
         for (int h = threadIdx.x; h < P.hn; h += RT) P.counts[bk * P.hn_pad + h] = 0;
         return;
     }
-    // ---- exact mode: the flagged cells of this (image, key-point), decided by the reference's arithmetic (round 5: the scoring
-    // kernel only lists them, CELL_CAP per (work item, wave)).  The quarters' fill counts are scanned RT at a time; 16 lanes take one
-    // cell -- one pixel row each, as the scoring kernel's own re-evaluation did -- and add its literal votes to the hypothesis' count.
-    if (!LITERAL && P.exact && !P.cull) {
-        __shared__ int s_excl[RT + 1];
-        __shared__ int s_wtot[RW];
-        const int HQ = P.hgroups / P.wg_g, nchg = (nchunks + P.wg_s - 1) / P.wg_s;
-        const size_t quarter0 = ((size_t)P.ctrl[bi * CTRL_STRIDE + C_ITEM_BASE] + (size_t)k * nchg * HQ) * 4;   // K3 planned the items in (key-point, pixel group, slice) order
-        const int nquarters = nchg * HQ * 4;
-        const int mh = P.wg_g * P.hpl / 2, npx = P.wg_s * P.chunk, ntiles = npx >> 5;
-        const int tn_ = P.ctrl[bi * CTRL_STRIDE + C_TN];
-        const int tpad = (tn_ + PAD - 1) / PAD * PAD;
-        const int grp = threadIdx.x >> 4, q = threadIdx.x & 15;
-        int ntests = 0;
-        for (int base = 0; base < nquarters; base += RT) {
-            const int qi = base + (int)threadIdx.x;
-            const int c = qi < nquarters ? P.cellcnt[quarter0 + qi] : 0;
-            int incl = c;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int u = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += u;
-            }
-            if (lane == 63) s_wtot[wave] = incl;
-            __syncthreads();
-            int off = 0, total = 0;
-#pragma unroll
-            for (int i = 0; i < RW; ++i) {
-                off += i < wave ? s_wtot[i] : 0;
-                total += s_wtot[i];
-            }
-            s_excl[threadIdx.x] = off + incl - c;
-            if (threadIdx.x == 0) s_excl[RT] = total;
-            __syncthreads();
-            for (int e = grp; e < total; e += RT / 16) {
-                int lo = 0;   // the quarter holding entry e: the last one whose exclusive prefix is <= e
-#pragma unroll
-                for (int st = RT / 2; st > 0; st >>= 1) lo += (s_excl[lo + st] <= e) ? st : 0;
-                const int quarter = base + lo, slot = e - s_excl[lo];
-                const unsigned cell = P.cells[(quarter0 + quarter) * CELL_CAP + slot];
-                const int rel = quarter >> 2, cg = rel / HQ, hq = rel - cg * HQ;
-                const int hl = (int)(cell & 1023u), hf = (int)((cell >> 10) & 1u);
-                unsigned m = cell >> 11;
-                const int hidx = hq * 4 * mh * 32 + hl;
-                const float2 hv = P.hyp[bk * P.hn_pad + hidx];
-                const int p0 = cg * npx;
-                const int left = (tpad - p0 + 31) >> 5, nti = left < ntiles ? left : ntiles;
-                const int row = (q >> 2) * 8 + hf * 4 + (q & 3);  // the 16 rows a lane of that half-wave holds
-                int votes = 0;
-                while (m) {
-                    const int g = __ffs((int)m) - 1;  // cells of one pixel tile: bit g = pixel tile nti - 1 - g (vote_slow_close shifts them in)
-                    m &= m - 1u;
-                    const int t0 = P.fold1 ? nti - 1 - g : 0, t1 = P.fold1 ? t0 + 1 : nti;
-                    for (int tile = t0; tile < t1; ++tile) {
-                        const int p = p0 + tile * 32 + row;
-                        if (p < tpad) {   // (records up to tpad exist: sentinels past tn never vote)
-                            const float4 r = P.rec[bk * P.cap + p];
-                            votes += inlier_literal(r.x, r.y, r.z, r.w, hv.x, hv.y, P.thresh) ? 1 : 0;
-                        }
-                        ++ntests;
-                    }
-                }
-                votes += __shfl_xor(votes, 8, 64);
-                votes += __shfl_xor(votes, 4, 64);
-                votes += __shfl_xor(votes, 2, 64);
-                votes += __shfl_xor(votes, 1, 64);
-                if (q == 0 && votes > 0) atomicAdd(P.counts + bk * P.hn_pad + hidx, votes);
-            }
-            __syncthreads();   // s_excl / s_wtot are rewritten by the next round
-        }
-        if ((P.flags & PVNET_F_BAND_STATS) && q == 0 && ntests > 0) atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 5, ntests);
-        __threadfence();   // the counts this workgroup has just completed are read below by its other threads
-        __syncthreads();
-    }
     // ---- counts = sum over chunks; winner = first maximum (:561-562).  A thread sums two adjacent hypotheses
     // (one 32-bit load per chunk row) with eight loads in flight: the rows are latency-, not bandwidth-bound.
     unsigned long long best = 0;
@@ -2479,8 +2408,7 @@ __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
         }
     } else if (P.atomic_counts) {  // K4 already summed: one value per hypothesis
         for (int h = threadIdx.x; h < P.hn; h += RT) {
-            // (an L2-coherent load: in exact mode this workgroup's own atomics above have just completed some of these counts)
-            const uint32_t c = (uint32_t)__hip_atomic_load(P.counts + bk * P.hn_pad + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t c = (uint32_t)P.counts[bk * P.hn_pad + h];
             const unsigned long long key = ((unsigned long long)c << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)h);
             best = key > best ? key : best;
         }
@@ -2914,7 +2842,7 @@ int layout_fingerprint(const PvnetVoteLayout& L) {
     uint64_t x = 0x9E3779B97F4A7C15ull;
     const uint64_t v[] = {(uint64_t)L.chunk, (uint64_t)L.hpl, (uint64_t)L.wg_g, (uint64_t)L.reserved_, (uint64_t)L.cap,
                           (uint64_t)L.hn_pad, (uint64_t)L.off_rec, (uint64_t)L.off_hyp, (uint64_t)L.off_counts,
-                          (uint64_t)L.off_win, (uint64_t)L.total_bytes, (uint64_t)L.cull, (uint64_t)L.off_perm, (uint64_t)L.off_cells};
+                          (uint64_t)L.off_win, (uint64_t)L.total_bytes, (uint64_t)L.cull, (uint64_t)L.off_perm};
     for (uint64_t e : v) { x ^= e + 0x9E3779B97F4A7C15ull + (x << 6) + (x >> 2); }
     const int fp = (int)(x ^ (x >> 32));
     return fp ? fp : 1;
@@ -3098,7 +3026,7 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
             const int mh = P.wg_g * P.hpl / 2;
             const int npx = P.wg_s * P.chunk;
             size_t lds = (size_t)(npx / 32) * TILE_U4 * sizeof(uint4) + (size_t)npx * sizeof(float4) +
-                         (size_t)4 * mh * 64 * sizeof(unsigned);   // A tiles, raw records, the waves' overflow cell lists
+                         (size_t)4 * mh * 32 * sizeof(float2) + (size_t)4 * mh * 64 * sizeof(unsigned);
             if (T.score_lds_kb > 0 && T.score_lds_kb <= 64 && lds < (size_t)T.score_lds_kb * 1024) lds = (size_t)T.score_lds_kb * 1024;
             const dim3 g((unsigned)wgs), t(256);
             const int fold = P.fold1;
@@ -3241,11 +3169,6 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     P.cnts = reinterpret_cast<int32_t*>(base + L.off_cnts);
     P.hypc = reinterpret_cast<uint4*>(base + L.off_hypc);
     P.hypg = reinterpret_cast<float*>(base + L.off_hypc + align_up(sizeof(uint4) * 2 * (size_t)b * vn * (L.hn_pad / 32), 256));
-    {
-        const size_t max_items = (size_t)b * vn * (L.hgroups / L.wg_g) * (size_t)((L.max_chunks + L.wg_s - 1) / L.wg_s);
-        P.cells = reinterpret_cast<uint32_t*>(base + L.off_cells);
-        P.cellcnt = reinterpret_cast<int32_t*>(base + L.off_cells + align_up(max_items * 4 * CELL_CAP * sizeof(uint32_t), 256));
-    }
     return 0;
 }
 
@@ -3332,9 +3255,6 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     L->off_cnts = take(L->cull ? sizeof(int32_t) * (size_t)b * vn * L->hn_pad : 0);
     // tile centres uint4 [b][vn][hn_pad / 32][2], then their g float [b][vn][hn_pad / 32]
     L->off_hypc = take(L->cull ? (sizeof(uint4) * 2 + sizeof(float)) * (size_t)b * vn * (L->hn_pad / 32) + 256 : 0);
-    // exact mode: flagged cells per (work item, wave) for K5 -- uint32 [items][4][CELL_CAP], then their counts int32 [items][4]
-    const size_t max_items = (size_t)b * vn * (hgroups / wg_g) * (size_t)((L->max_chunks + L->wg_s - 1) / L->wg_s);
-    L->off_cells = take(mode ? max_items * 4 * (CELL_CAP * sizeof(uint32_t) + sizeof(int32_t)) + 256 : 0);
     L->total_bytes = off;
     return 0;
 }

@@ -43,7 +43,7 @@ class Layout(C.Structure):
                                           "off_partial", "off_counts", "off_win", "off_seg", "off_items", "off_hypb",
                                           "total_bytes")] + \
                [("nseg", C.c_int32), ("wg_g", C.c_int32), ("wg_s", C.c_int32), ("reserved_", C.c_int32), ("cull", C.c_int32)] + \
-               [(n, C.c_size_t) for n in ("off_perm", "off_hyps", "off_cnts", "off_hypc", "off_cells")]
+               [(n, C.c_size_t) for n in ("off_perm", "off_hyps", "off_cnts", "off_hypc")]
 
 
 _lib = None
