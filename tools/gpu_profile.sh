@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-parity --streams 1 --prewarm-seconds 0.2 --regions 1"
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-parity --no-secondary --streams 1 --prewarm-seconds 0.2 --regions 1"   # (the profiled runs time the headline workload only: the secondary block runs other shapes through the same kernels)
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 3000 $OUT/bench.json
 # per-kernel durations (kernel trace only), then the counter passes, each in its own run (never together with other trace domains)
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $B --steps 200 --warmup 20 > $OUT/trace_bench.json 2> $OUT/trace.err )
