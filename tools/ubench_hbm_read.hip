@@ -144,6 +144,7 @@ int main() {
     run("16 B/lane, 8 loads in flight, 256 thr", rd<2, 8>, 256, 256 * 16);
     run("16 B/lane, 4 loads in flight, 512 thr", rd<2, 4>, 512, 512 * 8);
     run("16 B/lane, 16 loads in flight, 256 thr", rd<2, 16>, 256, 256 * 32);
+    run("8 B/lane, 8 loads in flight, 512 thr (K1's shape)", rd<1, 8>, 512, 512 * 8);
     unsigned long long* bits;
     int* seg;
     hipMalloc(&bits, n / 64 * 8 + 4096);
