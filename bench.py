@@ -184,12 +184,16 @@ def committed_profile(suffix):
     return tag, j.get("kernels", {}), j.get("source_hash") == source_hash()
 
 
+KERNEL_VARIANTS = {"mask_bits_kernel": ("mask_bits_kernel", "mask_bits_pair_kernel")}  # (round 5: aligned int64 masks take two pixels per 16-byte load)
+
+
 def pick_instantiation(kernels, base):
     """the instantiation of `base` with the most dispatches in the profiled run (the run also makes a few literal-mode
     calls, whose instantiations must not be mistaken for the timed ones)"""
     best = None
+    names = KERNEL_VARIANTS.get(base, (base,))
     for name, k in kernels.items():
-        if name.split("<")[0] == base and (best is None or k.get("n", 0) > kernels[best].get("n", 0)):
+        if name.split("<")[0] in names and (best is None or k.get("n", 0) > kernels[best].get("n", 0)):
             best = name
     return best
 
