@@ -253,6 +253,42 @@ def test_thinning_without_its_own_launch_edge_cases(max_num_of):
         assert np.abs(out.cpu().numpy() - ref)[ok].max() < 1e-3
 
 
+def test_int64_masks_at_every_alignment_give_the_same_pixel_lists():
+    """round 5: contiguous int64 masks at 16-byte aligned addresses with an even pixel count take two pixels per 16-byte load
+    (mask_bits_pair_kernel); the same mask 8 bytes further on, a strided view of it and an odd-sized image go through the
+    one-pixel-per-lane kernel.  Bit mask, counts, compacted pixel list, hypotheses and key-points must not depend on the route --
+    also where the thinning histogram is built (max_num below the foreground count)."""
+    mask, planar, _, _ = small_batch(b=3, h=120, w=162, radius=30)
+    m, v = to_dev(mask, planar)
+    assert m.dtype == torch.int64 and m.is_contiguous() and m.data_ptr() % 16 == 0 and (120 * 162) % 2 == 0
+    store = torch.zeros(m.numel() + 1, dtype=torch.int64, device=m.device)
+    store[1:] = m.reshape(-1)
+    shifted = store[1:].view_as(m)                      # the same values, 8 bytes off a 16-byte boundary
+    assert shifted.data_ptr() % 16 == 8
+    wide = torch.zeros((3, 120, 170), dtype=torch.int64, device=m.device)
+    wide[:, :, :162] = m
+    strided = wide[:, :, :162]                          # rows 170 elements apart: not linear
+    for max_num in (30000, 500):
+        ref, d0 = voting.ransac_voting_layer_v3(m, v, 96, inlier_thresh=0.99, seed=4, max_num=max_num, return_debug=True)
+        keep = {k: d0[k].clone() for k in ("bits", "tn0", "tn", "pix", "hyp", "counts")}
+        tns = [int(t) for t in keep["tn"][:3]]
+        ref = ref.clone()
+        for other in (shifted, strided):
+            out, d = voting.ransac_voting_layer_v3(other, v, 96, inlier_thresh=0.99, seed=4, max_num=max_num, return_debug=True)
+            for k, x in keep.items():
+                if k == "pix":   # (the list is written up to tn; what lies behind it is whatever the workspace held)
+                    for bi, tn in enumerate(tns):
+                        assert torch.equal(d[k][bi, :tn], x[bi, :tn]), (k, max_num, bi)
+                else:
+                    assert torch.equal(d[k], x), (k, max_num)
+            assert torch.equal(out, ref)
+    mo, po, _, _ = small_batch(b=2, h=99, w=101, radius=25)   # an odd number of pixels per image: odd images start 8 bytes off
+    m2, v2 = to_dev(mo, po)
+    a, da = voting.ransac_voting_layer_v3(m2, v2, 64, inlier_thresh=0.99, seed=5, return_debug=True)
+    b_, db = voting.ransac_voting_layer_v3(m2.to(torch.int32), v2, 64, inlier_thresh=0.99, seed=5, return_debug=True)
+    assert torch.equal(da["bits"], db["bits"]) and torch.equal(da["pix"][:, :200], db["pix"][:, :200]) and torch.equal(a, b_)
+
+
 @pytest.mark.parametrize("h,w,vn,hn", [(37, 53, 1, 100), (64, 64, 3, 33), (50, 200, 9, 520)])
 def test_odd_shapes(h, w, vn, hn):
     mask, planar, _ = synth.make_batch(2, first_index=560, h=h, w=w, vn=vn, radius=9, noise=True,
