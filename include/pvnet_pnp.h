@@ -52,6 +52,9 @@ int pvnet_pnp_solve(const double* pts2d, const double* pts3d, const double* wgt2
  * solve failed).  Returns the number of failed images, -1 on bad arguments. */
 int pvnet_pnp_solve_batch(const double* pts2d, const double* pts3d, const double* wgt2d, const double* K,
                           double* result_rt, int n, int pn);
+/* result_rt [n,6] of pvnet_pnp_solve_batch -> poses [n,3,4] = (R | t) row-major (zeros for a failed image): what `pnp` returns
+ * (lib/utils/evaluation_utils.py:50-52), for a whole batch without a Python loop. */
+void pvnet_pnp_poses_from_rt(const double* result_rt, double* poses, int n);
 
 /* angle-axis <-> rotation matrix (cv2.Rodrigues / ceres::AngleAxisToRotationMatrix), row-major R[9] */
 void pvnet_angle_axis_to_matrix(const double* aa, double* R);

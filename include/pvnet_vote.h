@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PVNET_VOTE_ABI_VERSION 8
+#define PVNET_VOTE_ABI_VERSION 9
 
 /* negative library error codes */
 #define PVNET_E_BADARG      (-1)   /* null pointer / non-positive size / unsupported dtype or stride */
@@ -102,8 +102,9 @@ typedef struct PvnetVoteLayout {
                                work item holds wg_g*64*hpl hypotheses = 4 waves x (wg_g*hpl/2) MFMA tiles of 32 */
     int32_t hgroups;        /* hypothesis groups per key-point = ceil(hn / (64*hpl)) rounded up to wg_g     */
     int32_t hn_pad;         /* hgroups * 64 * hpl                                                           */
-    size_t off_ctrl;        /* int32 [b][8]: tn0, tn, status, item_base, nchunks, origin x, origin y, -  ; then [8] global: total items, -,
-                               (2,3) stage-timer ticks, (4,5) band statistics (PVNET_F_BAND_STATS), (6) layout fingerprint */
+    size_t off_ctrl;        /* int32 [b][8]: tn0, tn, status, item_base, nchunks, origin x, origin y, -  ; then [8] global: total items,
+                               (1,7) culling statistics, (2,3) stage-timer ticks, (4,5) band statistics (PVNET_F_BAND_STATS), (6) layout
+                               fingerprint; then int32 [b][vn][2] band origins, then int32 [b][vn] 1 = key-point disc-culled */
     size_t off_bits;        /* uint64 [b][words]           foreground bit mask (as the mask has it: before thinning) */
     size_t off_pix;         /* int32  [b][cap]             linear pixel index y*w+x of compacted pixel t    */
     size_t off_rec;         /* float4 [b][vn][cap]         record (x, y, ux, uy): pixel and its RAW direction for the
@@ -122,13 +123,16 @@ typedef struct PvnetVoteLayout {
     int32_t nseg;           /* ceil(words / 64)                                                             */
     int32_t wg_g, wg_s;     /* a scoring workgroup covers wg_g hypothesis groups x wg_s chunks (wg_g*wg_s=4) */
     int32_t reserved_;      /* 1: fast mode scores on the matrix pipe (score_mfma_kernel), 0: VALU kernel                */
-    /* ABI 8 -- disc culling of the exact mode (pvnet_vote.hip: hypothesis_cull_kernel / score_exact_kernel_cull; PVNET_SCORE_CULL).
-     * Empty (cull = 0) unless the layout scores 8 hypothesis tiles per wave on 256-pixel work items with hn_pad <= 4096.        */
-    int32_t cull;           /* 1: exact-mode calls of this layout sort each key-point's hypotheses along a Hilbert curve and
+    /* ABI 8 / 9 -- disc culling of the exact mode (pvnet_vote.hip: cull_block of hypothesis_kernel / score_exact_kernel_cull).
+     * Empty (cull = 0) unless the layout scores 8 hypothesis tiles per wave on 256-pixel work items with hn_pad = 1024 and
+     * vn <= 32.  Which key-points of a call ARE culled is decided on the device per (image, key-point) -- from the spread of
+     * the candidate intersections of the band-origin estimate (PVNET_SCORE_CULL: 2 = that, the default; 1 = all; 0 = none) --
+     * and recorded as int32 [b][vn] behind the band origins in the ctrl block.  Culled or not, every count is the same integer. */
+    int32_t cull;           /* 1: exact-mode calls of this layout may sort a key-point's hypotheses along a Hilbert curve and
                                score only the (pixel, hypothesis tile) pairs whose outcome the tile's disc does not fix        */
     size_t off_perm;        /* int32  [b][vn][hn_pad]      sorted position -> caller's hypothesis index (>= hn: padding)        */
     size_t off_hyps;        /* float2 [b][vn][hn_pad]      hypotheses in sorted order                                          */
-    size_t off_cnts;        /* int32  [b][vn][hn_pad]      inlier counts in sorted order (`counts` holds them in CALLER order)  */
+    size_t off_cnts;        /* int32  [b][vn][hn_pad]      a culled key-point's counts in sorted order (`counts`: CALLER order, all)    */
     size_t off_hypc;        /* uint4  [b][vn][hn_pad/32][2] B column of every tile's centre, then float [b][vn][hn_pad/32] g    */
 } PvnetVoteLayout;
 

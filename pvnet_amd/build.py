@@ -48,7 +48,7 @@ def build_pnp(force: bool = False, verbose: bool = False) -> str:
     cxx = os.environ.get("CXX") or shutil.which("g++") or shutil.which("c++")
     if not cxx:
         raise RuntimeError("no C++ compiler found for libpvnet_pnp.so (set CXX)")
-    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"), PNP_SRC,
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-I", os.path.join(ROOT, "include"), PNP_SRC,
            "-o", PNP_LIB]
     if verbose:
         print(" ".join(cmd))

@@ -68,8 +68,11 @@ constexpr int SEG_WORDS = 64;          // a segment = 64 words = 4096 pixels: th
 #ifndef PVNET_SMALL_PRIO
 #define PVNET_SMALL_PRIO 3
 #endif
+#ifndef PVNET_CULL_Q_MILLI
+#define PVNET_CULL_Q_MILLI 250 // disc culling is selected for a key-point whose candidate intersections spread over <= 0.25 rho tan(theta0)
+#endif
 #ifndef PVNET_CULL_DEFAULT
-#define PVNET_CULL_DEFAULT 0   // what PVNET_SCORE_CULL = -1 (not set) means: 1 = disc culling where the layout supports it
+#define PVNET_CULL_DEFAULT 2   // what PVNET_SCORE_CULL = -1 (not set) means: 0 = never, 1 = every key-point, 2 = the key-points K3 selects
 #endif
 // the small latency-bound stages ask for issue priority over the co-resident scoring waves of other batches (s_setprio 3).
 // Round 1 measured nothing from it (nothing WAS resident beside the scoring kernel); since round 3 their workgroups share
@@ -138,10 +141,14 @@ struct VoteParams {
     float* out;
     int32_t* status;
     // disc culling (round 5; section "K4 -- disc culling" below): hypotheses sorted along a Hilbert curve per key-point
-    int cull;            // 1: this call scores with score_exact_kernel_cull (exact mode, 8 tiles per wave, 256-pixel items)
+    int cull;            // disc culling (exact mode, 8 tiles per wave, 256-pixel items, hn_pad = 1024): 0 = never, 1 = every key-point
+                         // (PVNET_SCORE_CULL=1), 2 = the key-points K3 selects (kp_preamble) -- the default where the layout supports it
+    float cull_q;        // selection threshold of cull = 2: spread of the candidate intersections <= cull_q rho tan(theta0)
     int32_t* perm;       // [b][vn][hn_pad] sorted position -> caller's hypothesis index
     float2* hyps;        // [b][vn][hn_pad] the hypotheses in sorted order (literal re-evaluation of flagged cells)
-    int32_t* cnts;       // [b][vn][hn_pad] inlier counts in sorted order (K4 accumulates; K5 returns them to caller order)
+    int32_t* cnts;       // [b][vn][hn_pad] inlier counts of the culled key-points in sorted order (K4 accumulates: 64 consecutive
+                         // slots per atomic -- adding at perm[] instead scattered every flush over ~28 cache lines and cost the strided
+                         // kernel 90 us, r06b; K5 returns them to caller order)
     uint4* hypc;         // [b][vn][hn_pad / 32][2] B column of every 32-hypothesis tile's CENTRE, scaled by 1 / (radius + band)
     float* hypg;         // [b][vn][hn_pad / 32]    g = radius term / (radius term + band term) of the tile (0: every pixel uncertain)
 };
@@ -806,8 +813,14 @@ __device__ __forceinline__ int plan_item_count(const VoteParams& P, int j, int* 
     return ((nch + P.wg_s - 1) / P.wg_s) * P.vn * (P.hgroups / P.wg_g);
 }
 
-template <int NT = 256>   // threads of the calling workgroup
-__device__ __forceinline__ void plan_image(const VoteParams& P, int bi) {
+// item descriptor (image, key-point | culled << 16, chunk group, hypothesis slice): the scoring kernels decode it with these
+constexpr int ITEM_CULL_SHIFT = 16;
+__device__ __forceinline__ int item_kp(int y) { return y & 0xFFFF; }
+__device__ __forceinline__ bool item_culled(int y) { return (y >> ITEM_CULL_SHIFT) != 0; }
+
+// kp_cull: [vn] 0 / 1 in LDS -- which key-points of this image the disc-culling kernel scores (nullptr: none)
+__device__ __forceinline__ void plan_image(const VoteParams& P, int bi, const int* kp_cull) {
+    constexpr int NT = 256;
     __shared__ int s_part[NT / 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int part = 0;
@@ -840,185 +853,18 @@ __device__ __forceinline__ void plan_image(const VoteParams& P, int bi) {
     const int HQ = P.hgroups / P.wg_g, nchg = (nch + P.wg_s - 1) / P.wg_s;
     for (int local = threadIdx.x; local < n; local += NT) {
         const int hq = local % HQ, t = local / HQ;
-        P.items[base + local] = make_int4(bi, t / nchg, t % nchg, hq);  // (image, key-point, chunk group, hyp slice)
+        const int k = t / nchg;
+        const int flag = (kp_cull && kp_cull[k]) ? (1 << ITEM_CULL_SHIFT) : 0;
+        P.items[base + local] = make_int4(bi, k | flag, t % nchg, hq);  // (image, key-point | culled, chunk group, hyp slice)
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // K3: hypotheses                                               (ransac_voting_gpu.py:547,554; kernel.cu:11-49)
+// One launch, three kinds of block per image (all of image bi on XCD bi % 8): ceil(hn vn / 256) blocks of one thread per (hypothesis,
+// key-point); one block that plans the scoring work items; and, where the layout supports disc culling, one block per key-point
+// that -- IF that key-point is culled -- sorts its hypotheses along a Hilbert curve and describes every tile of 32 by a disc.
 // ------------------------------------------------------------------------------------------------------------
-template <bool LITERAL>   // (amdgpu_num_vgpr: 40 usable of the 48 allocated -- the backend doubles the literal on this target)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(20))) void hypothesis_kernel(VoteParams P) {
-    PVNET_SPARE_VGPRS(47);
-    small_stage_prio();
-    // Workgroups go to the 8 XCDs round-robin by linear id; every block of image bi is placed on XCD bi % 8 so that
-    // the two random 16-byte record reads per hypothesis (several per 128-byte line of the image's records) hit
-    // that XCD's L2 after the first touch instead of crossing the fabric once per XCD.
-    const int nb = (P.hn * P.vn + 255) / 256 + 1;  // blocks per image, the last one plans
-    const int slot = blockIdx.x >> 3;
-    const int bi = (slot / nb) * 8 + (blockIdx.x & 7);
-    const int blk = slot % nb;
-    if (bi >= P.b) return;
-    if (blk == nb - 1) {      // one extra block per image plans its scoring work items
-        plan_image(P, bi);    // (consumed by the next launches only)
-        return;
-    }
-    const int i = blk * 256 + threadIdx.x;
-    const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
-    const bool live = P.ctrl[bi * CTRL_STRIDE + C_TN0] >= P.min_num && tn > 0;  // gates of :531-534
-    // Exact mode: the origin of the band per key-point (band_rho()).  Every block of the image works it out for itself (it
-    // needs it before it writes its first B column): eight candidate intersections per key-point from FIXED pixel pairs
-    // spread over the foreground list (records t and t + tn / 2), their component-wise median, rounded to integers.  It only
-    // scales the band -- no result depends on it -- so a bad estimate (fewer than three usable candidates: the image's median
-    // pixel instead) costs re-evaluations, never correctness.
-    constexpr int NCAND = 8, KP_MAX = 32;
-    __shared__ float s_cand[KP_MAX * NCAND * 2];
-    __shared__ int s_org[KP_MAX * 2];
-    __shared__ float s_med[KP_MAX * 2];
-    const bool kp_origin = !LITERAL && P.mode && P.exact && P.vn <= KP_MAX;   // block-uniform
-    // the thread's own hypothesis: its two records are requested NOW, so that they travel while the origin is worked out
-    const int hh = i / P.vn, hk = i - hh * P.vn;
-    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
-    if (live && i < P.hn * P.vn) {
-        int t0, t1;
-        if (P.idxs) {
-            t0 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2];
-            t1 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2 + 1];
-            t0 = t0 < 0 ? 0 : (t0 >= tn ? tn - 1 : t0);  // memory safety only; valid idxs are untouched
-            t1 = t1 < 0 ? 0 : (t1 >= tn ? tn - 1 : t1);
-        } else {
-            const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_HYP, (uint32_t)(P.image_base + bi));
-            t0 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u), (uint32_t)tn);
-            t1 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u + 1u), (uint32_t)tn);
-        }
-        q0 = P.rec[((size_t)bi * P.vn + hk) * P.cap + t0];  // (x, y, direction) of the two pixels
-        q1 = P.rec[((size_t)bi * P.vn + hk) * P.cap + t1];
-    }
-    if (kp_origin) {
-        int pm = 0;
-        if (live) pm = P.pix[(size_t)bi * P.cap + tn / 2];
-        if ((int)threadIdx.x < P.vn * NCAND) {
-            const int kk = threadIdx.x / NCAND, j = threadIdx.x % NCAND;
-            float cx = __uint_as_float(0x7FC00000u), cy = cx;   // NaN = no candidate
-            if (live) {
-                const int ta = (int)(((long long)(2 * j + 1) * tn) >> 4);
-                int tb = ta + tn / 2;
-                tb = tb >= tn ? tb - tn : tb;
-                const float4 q0 = P.rec[((size_t)bi * P.vn + kk) * P.cap + ta], q1 = P.rec[((size_t)bi * P.vn + kk) * P.cap + tb];
-                float hx0, hy0;
-                hyp_intersect(q0.z, q0.w, q0.x, q0.y, q1.z, q1.w, q1.x, q1.y, hx0, hy0);
-                if ((hx0 != 0.f || hy0 != 0.f) && fabsf(hx0) < 1048576.f && fabsf(hy0) < 1048576.f) { cx = hx0; cy = hy0; }
-            }
-            s_cand[threadIdx.x * 2] = cx;
-            s_cand[threadIdx.x * 2 + 1] = cy;
-        }
-        __syncthreads();
-        // median by rank, one thread per candidate (no arrays in registers: this kernel's 40-VGPR allocation is what lets two of
-        // its workgroups start beside a resident scoring kernel): candidate j is the median of a coordinate when n / 2 valid
-        // ones sort before it (NaN compares false: never counted, never the median)
-        const int kk = threadIdx.x / NCAND, j = threadIdx.x % NCAND;
-        const bool mine = (int)threadIdx.x < P.vn * NCAND;
-        const float* cand = s_cand + (mine ? kk : 0) * NCAND * 2;
-        int n = 0;
-        if (mine) {
-            int rx = 0, ry = 0;
-            const float vx = cand[2 * j], vy = cand[2 * j + 1];
-            for (int m2 = 0; m2 < NCAND; ++m2) {
-                const float ux = cand[2 * m2], uy = cand[2 * m2 + 1];
-                n += ux == ux ? 1 : 0;
-                rx += (ux < vx || (ux == vx && m2 < j)) ? 1 : 0;
-                ry += (uy < vy || (uy == vy && m2 < j)) ? 1 : 0;
-            }
-            if (vx == vx && rx == n / 2) s_med[kk * 2] = vx;
-            if (vy == vy && ry == n / 2) s_med[kk * 2 + 1] = vy;
-        }
-        __syncthreads();
-        if (mine && n >= 3) {   // the candidates' spread: the median of their (Chebyshev) distances from the median point
-            const float mx = s_med[kk * 2], my = s_med[kk * 2 + 1];
-            const float dj = fmaxf(fabsf(cand[2 * j] - mx), fabsf(cand[2 * j + 1] - my));
-            int rank = 0;
-            for (int m2 = 0; m2 < NCAND; ++m2) {
-                const float d2 = fmaxf(fabsf(cand[2 * m2] - mx), fabsf(cand[2 * m2 + 1] - my));
-                rank += (d2 < dj || (d2 == dj && m2 < j)) ? 1 : 0;
-            }
-            if (dj == dj && rank == n / 2) {
-                // Is the key-point a better origin than the median pixel?  With hypotheses spread S about it, at distance D from
-                // the object (radius Ro), the band bound (R + rho)(1 + r / rho) is about (S + rho)(1 + (D + Ro) / rho) there and
-                // (D + S + rho)(1 + Ro / rho) about the median pixel: take the smaller.  (Fields whose lines are nearly parallel
-                // scatter their intersections over 1e5 px: S ~ D -- the median pixel; the benchmark field: S ~ 3 px -- the key-point.)
-                const float rho = band_rho(tn), ro = rho * (1.f / 0.6f);
-                const float dist = fmaxf(fabsf(mx - (float)(pm % P.w)), fabsf(my - (float)(pm / P.w)));
-                const bool kp = (dj + rho) * (1.f + (dist + ro) / rho) < (dist + dj + rho) * (1.f + ro / rho);
-                s_org[kk * 2] = kp ? (int)rintf(mx) : pm % P.w;
-                s_org[kk * 2 + 1] = kp ? (int)rintf(my) : pm / P.w;
-            }
-        } else if (mine && j == 0) {   // fewer than three usable candidates
-            s_org[kk * 2] = pm % P.w;
-            s_org[kk * 2 + 1] = pm / P.w;
-        }
-        __syncthreads();
-        if (blk == 0 && (int)threadIdx.x < P.vn) {   // for the scoring kernel's staging (a_rows_exact)
-            int32_t* o = band_origin_ptr(P, (size_t)bi * P.vn + threadIdx.x);
-            o[0] = s_org[threadIdx.x * 2];
-            o[1] = s_org[threadIdx.x * 2 + 1];
-        }
-    } else if (!LITERAL && P.mode && P.exact && blk == 0) {   // more than KP_MAX key-points: the image's median pixel for all of them
-        int pm = 0;
-        if (live) pm = P.pix[(size_t)bi * P.cap + tn / 2];
-        for (int kk = threadIdx.x; kk < P.vn; kk += 256) {
-            int32_t* o = band_origin_ptr(P, (size_t)bi * P.vn + kk);
-            o[0] = pm % P.w;
-            o[1] = pm / P.w;
-        }
-    }
-    if (i < P.hn * P.vn) {
-    const int h = hh, k = hk;
-    float hx = 0.f, hy = 0.f;
-    if (live) {
-        const float2 d0 = rec_dir(q0), d1 = rec_dir(q1);
-        hyp_intersect(d0.x, d0.y, q0.x, q0.y, d1.x, d1.y, q1.x, q1.y, hx, hy);
-    }
-    P.hyp[((size_t)bi * P.vn + k) * P.hn_pad + h] = make_float2(hx, hy);
-    if (P.atomic_counts) P.counts[((size_t)bi * P.vn + k) * P.hn_pad + h] = 0;  // K4 accumulates into it
-    if (!LITERAL && P.mode) {  // the same hypothesis about the image's local origin, as a bf16x3 B operand column
-        float ox = 0.f, oy = 0.f;
-        if (kp_origin) {
-            ox = (float)s_org[k * 2];
-            oy = (float)s_org[k * 2 + 1];
-        } else if (live) {
-            const int pm = P.pix[(size_t)bi * P.cap + tn / 2];  // the origin plan_image() records for this image
-            ox = (float)(pm % P.w);
-            oy = (float)(pm / P.w);
-        }
-        uint4 lo, hi;
-        if (P.exact) b_col_exact(hx - ox, hy - oy, band_rho(tn), P.kband, lo, hi);
-        else b_col(hx - ox, hy - oy, lo, hi);
-        uint4* o = P.hypb + (((size_t)bi * P.vn + k) * P.hn_pad + h) * 2;
-        o[0] = lo;
-        o[1] = hi;
-    }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// K3 for the disc-culling scoring kernel (round 5): one workgroup per (image, key-point) generates the key-point's hypotheses
-// (the same draws, the same arithmetic, the same caller-order `hyp` array as hypothesis_kernel), SORTS them along a Hilbert curve
-// about the band origin so that every 32 consecutive ones -- one MFMA hypothesis tile -- lie close together, and describes each
-// tile by a disc: centre q (bounding-box centre), radius rho_T.  The scoring kernel tests every pixel ONCE against the centre of
-// each tile (one MFMA pair per 32 pixels x 32 tiles) and only gathers the pixels whose vote is not the same for the whole disc.
-//   sorted order : hypb (B columns), hyps (raw hypotheses, for the literal re-evaluation), cnts (counts), perm (-> caller index)
-//   per tile     : hypc = the B column of the centre at scale s' = 0.9 / (G + E), hypg = g = G / (G + E), with
-//                  G = rho_T / thresh   (|m(h) - m(q)| <= |h - q| / cos theta0: the margin's Lipschitz constant) and
-//                  E = kband (R_q + rho_T + rho)   (rounding band of every hypothesis of the disc + the matrix pipe's own error)
-// A pixel i with row scale |M_i| <= mu_i is CERTAIN for the tile when |x'| >= 1 - g (1 - mu_i), x' = s' |M_i| m_i(q) as the two
-// MFMAs return it: then |m_i(q)| > rho_T / thresh + band, so m_i has one sign on the whole disc and the reference's float32 test
-// agrees with it for every hypothesis of the tile (derivation: DESIGN.md section 4, "disc culling").
-// Padding hypotheses (>= hn) sort to the end; a tile without a real hypothesis is never scored.
-// ------------------------------------------------------------------------------------------------------------
-constexpr int CULL_NPX = 256;              // pixels per work item of the culling kernel: 8 pixel tiles, list entries are 16-bit
-constexpr int CULL_MAX_HN = 4096;          // hypotheses per key-point the sort handles in LDS (hn_pad)
-constexpr int CULL_DEAD = 8 * TILE_U4_;    // uint4 index of the dead A row behind the item's 8 tiles (x = -4: no vote, no flag)
-
 // position of (x, y) on the Hilbert curve of a 2^bits x 2^bits grid (consecutive positions are neighbouring cells)
 __device__ __forceinline__ uint32_t hilbert_index(uint32_t x, uint32_t y, int bits) {
     uint32_t d = 0;
@@ -1033,204 +879,229 @@ __device__ __forceinline__ uint32_t hilbert_index(uint32_t x, uint32_t y, int bi
     return d;
 }
 
-constexpr int CULL_K3_THREADS = 1024;   // one hypothesis per thread at 1 024 hypotheses (up to four at 4 096)
-__global__ __launch_bounds__(CULL_K3_THREADS) void hypothesis_cull_kernel(VoteParams P) {
-    PVNET_SPARE_VGPRS(63);
-    small_stage_prio();
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = CULL_K3_THREADS, EMAX = CULL_MAX_HN / NT;
-    // blocks of image bi on XCD bi % 8 (its records pass through one L2, as in hypothesis_kernel); vn + 1 blocks per image, the last plans
-    const int nb = P.vn + 1;
-    const int slot = blockIdx.x >> 3;
-    const int bi = (slot / nb) * 8 + (blockIdx.x & 7);
-    const int k = slot % nb;
-    if (bi >= P.b) return;
-    if (k == P.vn) {
-        plan_image<NT>(P, bi);
-        return;
-    }
-    const int tid = threadIdx.x;
-    const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
-    const bool live = P.ctrl[bi * CTRL_STRIDE + C_TN0] >= P.min_num && tn > 0;  // gates of :531-534
-    const size_t bk = (size_t)bi * P.vn + k;
-    float2* s_h = reinterpret_cast<float2*>(smem);                  // [hn_pad] hypotheses, caller order
-    uint32_t* s_key = reinterpret_cast<uint32_t*>(s_h + P.hn_pad);  // [n2] exchange buffer of the sort's cross-wave stages
-    int n2 = NT;
-    while (n2 < P.hn_pad) n2 <<= 1;           // 1 024, 2 048 or 4 096 sort slots: E = n2 / 1 024 per thread, slot = e * 1 024 + tid
-    const int E = n2 / NT;
-    const int idxbits = 31 - __clz(n2);
-    const int cbits = (32 - idxbits) >> 1;   // bits per coordinate of the key: 11 at 1 024 hypotheses (+-128 px in 1/8 px), 10 at 4 096
-    constexpr int NCAND = 8;
-    __shared__ float s_cand[NCAND * 2];
-    __shared__ float s_med[2];
-    __shared__ int s_org[2];
-    const float rho = band_rho(tn);
+constexpr int CULL_NPX = 256;              // pixels per work item of the culling kernel: 8 pixel tiles, list entries are 16-bit
+constexpr int CULL_HN = 1024;              // hypotheses per key-point (hn_pad) of the layouts that can cull: one hypothesis slice, 32 tiles,
+                                           // four sort keys per thread of a 256-thread block
+constexpr int CULL_DEAD = 8 * TILE_U4_;    // uint4 index of the dead A row behind the item's 8 tiles (x = -4: no vote, no flag)
+constexpr int NCAND = 8, KP_MAX = 32;      // candidate intersections per key-point of the origin estimate; key-points it handles
 
-    // ---- the band origin of this key-point: the same estimate as hypothesis_kernel's (eight fixed pixel pairs, component-wise median,
-    //      the median pixel when the candidates scatter or fewer than three are usable)
+// What every K3 block works out for itself about its image before anything else (cheap -- 8 vn intersections -- and no block then
+// waits for another): per key-point the ORIGIN of the exact mode's rounding band and whether the key-point is DISC-CULLED.
+//   origin   eight candidate intersections from FIXED pixel pairs spread over the foreground list (records t and t + tn / 2), their
+//            component-wise median, rounded to integers.  It only scales the band -- no result depends on it -- so a bad estimate
+//            (fewer than three usable candidates: the image's median pixel instead) costs re-evaluations, never correctness.
+//   culling  P.cull = 1: every key-point (PVNET_SCORE_CULL=1: tests and probes); P.cull = 2 (the default where the layout supports
+//            it): the key-points whose candidates lie close together -- spread S (median Chebyshev distance from the median point)
+//            <= cull_q rho tan(theta0), i.e. the field's angular noise is small against the threshold angle, so most pixels are
+//            certain for most hypothesis tiles and the gathered rest is cheaper than the dense sweep (crossover measured:
+//            profiles/r06_cull_crossover.txt).  Any choice gives the same counts; a wrong one only costs time.
+struct KpShared {
+    float cand[KP_MAX * NCAND * 2];
+    float med[KP_MAX * 2];
+    int org[KP_MAX * 2];
+    int cull[KP_MAX];
+};
+__device__ __forceinline__ void kp_preamble(const VoteParams& P, int bi, int tn, bool live, KpShared& S) {
     int pm = 0;
     if (live) pm = P.pix[(size_t)bi * P.cap + tn / 2];
-    if (tid < NCAND) {
+    const int kk = threadIdx.x / NCAND, j = threadIdx.x % NCAND;
+    const bool mine = (int)threadIdx.x < P.vn * NCAND;
+    if (mine) {
         float cx = __uint_as_float(0x7FC00000u), cy = cx;   // NaN = no candidate
         if (live) {
-            const int ta = (int)(((long long)(2 * tid + 1) * tn) >> 4);
+            const int ta = (int)(((long long)(2 * j + 1) * tn) >> 4);
             int tb = ta + tn / 2;
             tb = tb >= tn ? tb - tn : tb;
-            const float4 q0 = P.rec[bk * P.cap + ta], q1 = P.rec[bk * P.cap + tb];
+            const float4 q0 = P.rec[((size_t)bi * P.vn + kk) * P.cap + ta], q1 = P.rec[((size_t)bi * P.vn + kk) * P.cap + tb];
             float hx0, hy0;
             hyp_intersect(q0.z, q0.w, q0.x, q0.y, q1.z, q1.w, q1.x, q1.y, hx0, hy0);
             if ((hx0 != 0.f || hy0 != 0.f) && fabsf(hx0) < 1048576.f && fabsf(hy0) < 1048576.f) { cx = hx0; cy = hy0; }
         }
-        s_cand[tid * 2] = cx;
-        s_cand[tid * 2 + 1] = cy;
-    }
-    // ---- this key-point's hypotheses (kernel.cu:11-49), caller order: thread t takes h = t, t + 1 024, ...; the record loads of
-    //      all of a thread's hypotheses are issued before the first intersection
-    float4 qa[EMAX], qb[EMAX];
-#pragma unroll
-    for (int e = 0; e < EMAX; ++e) {
-        const int h = e * NT + tid;
-        qa[e] = qb[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live && h < P.hn) {
-            const int i = h * P.vn + k;   // the draw's index in the reference's [hn, vn, 2] layout
-            int t0, t1;
-            if (P.idxs) {
-                t0 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2];
-                t1 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2 + 1];
-                t0 = t0 < 0 ? 0 : (t0 >= tn ? tn - 1 : t0);  // memory safety only; valid idxs are untouched
-                t1 = t1 < 0 ? 0 : (t1 >= tn ? tn - 1 : t1);
-            } else {
-                const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_HYP, (uint32_t)(P.image_base + bi));
-                t0 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u), (uint32_t)tn);
-                t1 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u + 1u), (uint32_t)tn);
-            }
-            qa[e] = P.rec[bk * P.cap + t0];
-            qb[e] = P.rec[bk * P.cap + t1];
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < EMAX; ++e) {
-        const int h = e * NT + tid;
-        if (h < P.hn_pad) {
-            float hx = 0.f, hy = 0.f;
-            if (live && h < P.hn) hyp_intersect(qa[e].z, qa[e].w, qa[e].x, qa[e].y, qb[e].z, qb[e].w, qb[e].x, qb[e].y, hx, hy);
-            s_h[h] = make_float2(hx, hy);
-            if (h < P.hn) P.hyp[bk * P.hn_pad + h] = make_float2(hx, hy);
-        }
+        S.cand[threadIdx.x * 2] = cx;
+        S.cand[threadIdx.x * 2 + 1] = cy;
     }
     __syncthreads();
-    {   // median by rank, as in hypothesis_kernel (one key-point here)
-        const int j = tid % NCAND;
-        const bool mine = tid < NCAND;
-        int n = 0;
-        if (mine) {
-            int rx = 0, ry = 0;
-            const float vx = s_cand[2 * j], vy = s_cand[2 * j + 1];
-            for (int m2 = 0; m2 < NCAND; ++m2) {
-                const float ux = s_cand[2 * m2], uy = s_cand[2 * m2 + 1];
-                n += ux == ux ? 1 : 0;
-                rx += (ux < vx || (ux == vx && m2 < j)) ? 1 : 0;
-                ry += (uy < vy || (uy == vy && m2 < j)) ? 1 : 0;
-            }
-            if (vx == vx && rx == n / 2) s_med[0] = vx;
-            if (vy == vy && ry == n / 2) s_med[1] = vy;
+    // median by rank, one thread per candidate (no arrays in registers: this kernel's small VGPR allocation is what lets two of
+    // its workgroups start beside a resident scoring kernel): candidate j is the median of a coordinate when n / 2 valid
+    // ones sort before it (NaN compares false: never counted, never the median)
+    const float* cand = S.cand + (mine ? kk : 0) * NCAND * 2;
+    int n = 0;
+    if (mine) {
+        int rx = 0, ry = 0;
+        const float vx = cand[2 * j], vy = cand[2 * j + 1];
+        for (int m2 = 0; m2 < NCAND; ++m2) {
+            const float ux = cand[2 * m2], uy = cand[2 * m2 + 1];
+            n += ux == ux ? 1 : 0;
+            rx += (ux < vx || (ux == vx && m2 < j)) ? 1 : 0;
+            ry += (uy < vy || (uy == vy && m2 < j)) ? 1 : 0;
         }
-        __syncthreads();
-        if (mine && n >= 3) {
-            const float mx = s_med[0], my = s_med[1];
-            const float dj = fmaxf(fabsf(s_cand[2 * j] - mx), fabsf(s_cand[2 * j + 1] - my));
-            int rank = 0;
-            for (int m2 = 0; m2 < NCAND; ++m2) {
-                const float d2 = fmaxf(fabsf(s_cand[2 * m2] - mx), fabsf(s_cand[2 * m2 + 1] - my));
-                rank += (d2 < dj || (d2 == dj && m2 < j)) ? 1 : 0;
-            }
-            if (dj == dj && rank == n / 2) {
-                const float ro = rho * (1.f / 0.6f);
-                const float dist = fmaxf(fabsf(mx - (float)(pm % P.w)), fabsf(my - (float)(pm / P.w)));
-                const bool kp = (dj + rho) * (1.f + (dist + ro) / rho) < (dist + dj + rho) * (1.f + ro / rho);
-                s_org[0] = kp ? (int)rintf(mx) : pm % P.w;
-                s_org[1] = kp ? (int)rintf(my) : pm / P.w;
-            }
-        } else if (mine && j == 0) {   // fewer than three usable candidates
-            s_org[0] = pm % P.w;
-            s_org[1] = pm / P.w;
+        if (vx == vx && rx == n / 2) S.med[kk * 2] = vx;
+        if (vy == vy && ry == n / 2) S.med[kk * 2 + 1] = vy;
+    }
+    __syncthreads();
+    if (mine && n >= 3) {   // the candidates' spread: the median of their (Chebyshev) distances from the median point
+        const float mx = S.med[kk * 2], my = S.med[kk * 2 + 1];
+        const float dj = fmaxf(fabsf(cand[2 * j] - mx), fabsf(cand[2 * j + 1] - my));
+        int rank = 0;
+        for (int m2 = 0; m2 < NCAND; ++m2) {
+            const float d2 = fmaxf(fabsf(cand[2 * m2] - mx), fabsf(cand[2 * m2 + 1] - my));
+            rank += (d2 < dj || (d2 == dj && m2 < j)) ? 1 : 0;
         }
-        __syncthreads();
+        if (dj == dj && rank == n / 2) {
+            // Is the key-point a better origin than the median pixel?  With hypotheses spread S about it, at distance D from
+            // the object (radius Ro), the band bound (R + rho)(1 + r / rho) is about (S + rho)(1 + (D + Ro) / rho) there and
+            // (D + S + rho)(1 + Ro / rho) about the median pixel: take the smaller.  (Fields whose lines are nearly parallel
+            // scatter their intersections over 1e5 px: S ~ D -- the median pixel; the benchmark field: S ~ 3 px -- the key-point.)
+            const float rho = band_rho(tn), ro = rho * (1.f / 0.6f);
+            const float dist = fmaxf(fabsf(mx - (float)(pm % P.w)), fabsf(my - (float)(pm / P.w)));
+            const bool kp = (dj + rho) * (1.f + (dist + ro) / rho) < (dist + dj + rho) * (1.f + ro / rho);
+            S.org[kk * 2] = kp ? (int)rintf(mx) : pm % P.w;
+            S.org[kk * 2 + 1] = kp ? (int)rintf(my) : pm / P.w;
+            S.cull[kk] = P.cull == 1 || (P.cull == 2 && kp && dj <= P.cull_q * rho * P.tau) ? 1 : 0;
+        }
+    } else if (mine && j == 0) {   // fewer than three usable candidates
+        S.org[kk * 2] = pm % P.w;
+        S.org[kk * 2 + 1] = pm / P.w;
+        S.cull[kk] = (P.cull == 1 && live) ? 1 : 0;
     }
-    const float ox = (float)s_org[0], oy = (float)s_org[1];
-    if (tid == 0) {   // for the scoring kernel's staging (a_rows_exact)
-        int32_t* o = band_origin_ptr(P, bk);
-        o[0] = s_org[0];
-        o[1] = s_org[1];
+    __syncthreads();
+}
+
+// The block of a CULLED key-point: generates the key-point's hypotheses once more (the same draws, the same arithmetic as the
+// hypothesis blocks, which write the caller-order `hyp` array and zero `counts`), SORTS them along a Hilbert curve about the band
+// origin so that every 32 consecutive ones -- one MFMA hypothesis tile -- lie close together, and describes each tile by a disc:
+// centre q (bounding-box centre), radius rho_T.  The scoring kernel tests every pixel ONCE against the centre of each tile (one
+// MFMA pair per 32 pixels x 32 tiles) and only gathers the pixels whose vote is not the same for the whole disc.
+//   sorted order : hypb (B columns), hyps (raw hypotheses, for the literal re-evaluation), perm (-> caller index: where the counts go)
+//   per tile     : hypc = the B column of the centre at scale s' = 0.9 / (G + E), hypg = g = G / (G + E), with
+//                  G = rho_T / thresh   (|m(h) - m(q)| <= |h - q| / cos theta0: the margin's Lipschitz constant) and
+//                  E = kband (R_q + rho_T + rho)   (rounding band of every hypothesis of the disc + the matrix pipe's own error)
+// A pixel i with row scale |M_i| <= mu_i is CERTAIN for the tile when |x'| >= 1 - g (1 - mu_i), x' = s' |M_i| m_i(q) as the two
+// MFMAs return it: then |m_i(q)| > rho_T / thresh + band, so m_i has one sign on the whole disc and the reference's float32 test
+// agrees with it for every hypothesis of the tile (derivation: DESIGN.md section 4, "disc culling").
+// Padding hypotheses (>= hn) sort to the end; a tile without a real hypothesis is never scored.
+// Round 6: 256 threads with four keys each (round 5: 1 024 threads, one key each, 40 us for 288 blocks -- two rounds on 256 CUs and
+// sixteen waves per barrier); a block of four waves is resident wherever a hypothesis block is.
+// (-DPVNET_K3_PROBE, tools/experiments/k3_probe.py: shader-clock stamps of the block's phases into the unused tail of the item list)
+#ifdef PVNET_K3_PROBE
+#define PV_K3_STAMP(i) do { if (threadIdx.x == 0) k3_stamp[i] = (int)(clock64() - k3_t0); } while (0)
+#else
+#define PV_K3_STAMP(i) do { } while (0)
+#endif
+__device__ __forceinline__ void cull_block(const VoteParams& P, int bi, int k, int tn, const KpShared& S, float2* s_h, uint32_t* s_key,
+                                           long long k3_t0) {
+    constexpr int NT = 256, E = CULL_HN / NT;
+    const int tid = threadIdx.x;
+    const size_t bk = (size_t)bi * P.vn + k;
+#ifdef PVNET_K3_PROBE
+    const long long max_items = (long long)P.b * P.vn * (P.hgroups / P.wg_g) * ((P.max_chunks + P.wg_s - 1) / P.wg_s);
+    int* const k3_stamp = reinterpret_cast<int*>(P.items + (max_items - 2 - 2 * (long long)bk));
+#endif
+    PV_K3_STAMP(0);   // preamble done
+    const float rho = band_rho(tn);
+    const float ox = (float)S.org[k * 2], oy = (float)S.org[k * 2 + 1];
+    // ---- this key-point's hypotheses (kernel.cu:11-49), caller order: thread t takes h = t, t + 256, ...; two hypotheses (four
+    //      record loads) in flight per thread
+#pragma unroll
+    for (int e0 = 0; e0 < E; e0 += 2) {
+        float4 qa[2], qb[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int h = (e0 + u) * NT + tid;
+            qa[u] = qb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (h < P.hn) {
+                const int i = h * P.vn + k;   // the draw's index in the reference's [hn, vn, 2] layout
+                int t0, t1;
+                if (P.idxs) {
+                    t0 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2];
+                    t1 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2 + 1];
+                    t0 = t0 < 0 ? 0 : (t0 >= tn ? tn - 1 : t0);  // memory safety only; valid idxs are untouched
+                    t1 = t1 < 0 ? 0 : (t1 >= tn ? tn - 1 : t1);
+                } else {
+                    const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_HYP, (uint32_t)(P.image_base + bi));
+                    t0 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u), (uint32_t)tn);
+                    t1 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u + 1u), (uint32_t)tn);
+                }
+                qa[u] = P.rec[bk * P.cap + t0];
+                qb[u] = P.rec[bk * P.cap + t1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int h = (e0 + u) * NT + tid;
+            float hx = 0.f, hy = 0.f;
+            if (h < P.hn) hyp_intersect(qa[u].z, qa[u].w, qa[u].x, qa[u].y, qb[u].z, qb[u].w, qb[u].x, qb[u].y, hx, hy);
+            s_h[h] = make_float2(hx, hy);
+        }
     }
-    // ---- sort keys: position on a Hilbert curve of 1/8-pixel cells about the origin; far and non-finite hypotheses clamp to the border
-    uint32_t key[EMAX];
+    PV_K3_STAMP(1);   // hypotheses
+    // ---- sort keys: position on a Hilbert curve of 1/8-pixel cells about the origin (11 bits per coordinate: +-128 px); far and
+    //      non-finite hypotheses clamp to the border.  (a thread reads back only what it wrote: no barrier yet)
+    constexpr int idxbits = 10, cbits = (32 - idxbits) >> 1;
+    uint32_t key[E];
     {
         const float cells = (float)(1 << cbits);
 #pragma unroll
-        for (int e = 0; e < EMAX; ++e) {
+        for (int e = 0; e < E; ++e) {
             const int h = e * NT + tid;
-            uint32_t kv = 0xFFFFFFFFu;   // (slots beyond hn_pad, and the registers beyond E: behind everything)
+            uint32_t kv = (0xFFFFFFFFu << idxbits) | (uint32_t)h;   // padding: behind every real hypothesis (ties broken by the index)
             if (h < P.hn) {
                 const float2 hv = s_h[h];
                 const float fx = fminf(fmaxf((hv.x - ox) * 8.f + 0.5f * cells, 0.f), cells - 1.f);   // (NaN -> 0)
                 const float fy = fminf(fmaxf((hv.y - oy) * 8.f + 0.5f * cells, 0.f), cells - 1.f);
                 kv = (hilbert_index((uint32_t)fx, (uint32_t)fy, cbits) << idxbits) | (uint32_t)h;
-            } else if (h < P.hn_pad) {
-                kv = (0xFFFFFFFFu << idxbits) | (uint32_t)h;   // padding: behind every real hypothesis (ties broken by the index)
             }
             key[e] = kv;
         }
     }
-    // ---- bitonic sort, ascending, slot i = e * 1 024 + tid: partners 1 .. 32 lanes away by shuffle, 64 .. 512 threads away through
-    //      LDS (two barriers), 1 024 / 2 048 slots away in the thread's own registers
+    PV_K3_STAMP(2);   // keys
+    // ---- bitonic sort, ascending, slot i = e * 256 + tid: partners 1 .. 32 lanes away by shuffle, 64 / 128 threads away through
+    //      LDS (two barriers), 256 / 512 slots away in the thread's own registers
     auto cas = [&](uint32_t& mine_, uint32_t other, int i, int kk, int jj) {
         const bool keep_min = ((i & jj) == 0) == ((i & kk) == 0);
         const uint32_t lo = mine_ < other ? mine_ : other, hi = mine_ < other ? other : mine_;
         mine_ = keep_min ? lo : hi;
     };
-    for (int kk = 2; kk <= n2; kk <<= 1)
+    for (int kk = 2; kk <= CULL_HN; kk <<= 1)
         for (int jj = kk >> 1; jj > 0; jj >>= 1) {
             if (jj >= NT) {   // (block-uniform)
                 if (jj == NT) {
                     { const uint32_t a = key[0], c = key[1]; cas(key[0], c, tid, kk, jj); cas(key[1], a, NT + tid, kk, jj); }
-                    if (E > 2) { const uint32_t a = key[2], c = key[3]; cas(key[2], c, 2 * NT + tid, kk, jj); cas(key[3], a, 3 * NT + tid, kk, jj); }
+                    { const uint32_t a = key[2], c = key[3]; cas(key[2], c, 2 * NT + tid, kk, jj); cas(key[3], a, 3 * NT + tid, kk, jj); }
                 } else {
                     { const uint32_t a = key[0], c = key[2]; cas(key[0], c, tid, kk, jj); cas(key[2], a, 2 * NT + tid, kk, jj); }
                     { const uint32_t a = key[1], c = key[3]; cas(key[1], c, NT + tid, kk, jj); cas(key[3], a, 3 * NT + tid, kk, jj); }
                 }
             } else if (jj >= 64) {
 #pragma unroll
-                for (int e = 0; e < EMAX; ++e)
-                    if (e < E) s_key[e * NT + tid] = key[e];
+                for (int e = 0; e < E; ++e) s_key[e * NT + tid] = key[e];
                 __syncthreads();
 #pragma unroll
-                for (int e = 0; e < EMAX; ++e)
-                    if (e < E) cas(key[e], s_key[(e * NT + tid) ^ jj], e * NT + tid, kk, jj);
+                for (int e = 0; e < E; ++e) cas(key[e], s_key[(e * NT + tid) ^ jj], e * NT + tid, kk, jj);
                 __syncthreads();
             } else {
 #pragma unroll
-                for (int e = 0; e < EMAX; ++e)
-                    if (e < E) cas(key[e], (uint32_t)__shfl_xor((int)key[e], jj, 64), e * NT + tid, kk, jj);
+                for (int e = 0; e < E; ++e) cas(key[e], (uint32_t)__shfl_xor((int)key[e], jj, 64), e * NT + tid, kk, jj);
             }
         }
-    // ---- sorted outputs + one disc per tile of 32 sorted hypotheses: a tile = the 32 lanes of a half-wave (slot p = e * 1 024 + tid)
-    const uint32_t imask = (uint32_t)n2 - 1u;
-    const int ntl = P.hn_pad >> 5;
+    __syncthreads();   // (s_h of the other threads: every hypothesis has been written -- the sort's own barriers already saw to it)
+    PV_K3_STAMP(3);   // sort
+    // ---- sorted outputs + one disc per tile of 32 sorted hypotheses: a tile = the 32 lanes of a half-wave (slot p = e * 256 + tid)
+    constexpr uint32_t imask = (uint32_t)CULL_HN - 1u;
+    constexpr int ntl = CULL_HN >> 5;
 #pragma unroll
-    for (int e = 0; e < EMAX; ++e) {
+    for (int e = 0; e < E; ++e) {
         const int p = e * NT + tid;
-        if (p >= P.hn_pad) continue;   // (uniform per half-wave: hn_pad is a multiple of 32)
         const int j = (int)(key[e] & imask);
         const bool real = j < P.hn;
         const float2 hv = real ? s_h[j] : make_float2(0.f, 0.f);
-        P.perm[bk * P.hn_pad + p] = j;
-        P.hyps[bk * P.hn_pad + p] = hv;
-        P.cnts[bk * P.hn_pad + p] = 0;   // K4 accumulates into it
+        P.perm[bk * CULL_HN + p] = j;
+        P.hyps[bk * CULL_HN + p] = hv;
+        P.cnts[bk * CULL_HN + p] = 0;   // K4 accumulates into it
         const float hxo = hv.x - ox, hyo = hv.y - oy;
         uint4 lo = make_uint4(0u, 0u, 0u, 0u), hi = make_uint4(0u, 0u, 0u, pk(0u, 0x3F80u));
         if (real) b_col_exact(hxo, hyo, rho, P.kband, lo, hi);
-        uint4* o = P.hypb + (bk * P.hn_pad + p) * 2;
+        uint4* o = P.hypb + (bk * CULL_HN + p) * 2;
         o[0] = lo;
         o[1] = hi;
         // the tile's bounding box, whether it holds a far / non-finite hypothesis, how many real ones: over the 32 lanes
@@ -1262,10 +1133,10 @@ __global__ __launch_bounds__(CULL_K3_THREADS) void hypothesis_cull_kernel(VotePa
                 const float rtu = rt + 4.0e-7f * (Rq + rt);
                 const float G = rtu / P.thresh * 1.000001f;
                 const float Eb = P.kband * (Rq + rtu + rho);
-                const float S = G + Eb;
-                const float sc = bf16_floor(BAND_TARGET / S);
+                const float Sg = G + Eb;
+                const float sc = bf16_floor(BAND_TARGET / Sg);
                 b_col_scaled(qx, qy, Rq + rtu, sc, clo, chi);
-                if (sc > 0.f && Rq + rtu < BAND_FAR) g = G / S * 0.99999f;   // (rounded down: the certainty threshold 1 - g (1 - mu) only grows)
+                if (sc > 0.f && Rq + rtu < BAND_FAR) g = G / Sg * 0.99999f;   // (rounded down: the certainty threshold 1 - g (1 - mu) only grows)
             }
             const int T = p >> 5;
             uint4* oc = P.hypc + (bk * ntl + T) * 2;
@@ -1273,6 +1144,114 @@ __global__ __launch_bounds__(CULL_K3_THREADS) void hypothesis_cull_kernel(VotePa
             oc[1] = chi;
             P.hypg[bk * ntl + T] = g;
         }
+    }
+    PV_K3_STAMP(4);   // outputs issued
+}
+
+// which key-points of which image are disc-culled: int32 [b][vn] behind the band origins (the scoring kernels' flag travels in the
+// item descriptors; this copy is for the epilogues that read a finished workspace: band_margin_kernel, the debug views)
+__device__ __forceinline__ int32_t* kp_cull_ptr(const VoteParams& P, size_t bk) {
+    return P.ctrl + (size_t)(P.b + 1) * CTRL_STRIDE + 2 * (size_t)P.b * P.vn + bk;
+}
+
+template <bool LITERAL>   // (amdgpu_num_vgpr: 40 usable of the 48 allocated -- the backend doubles the literal on this target)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(20))) void hypothesis_kernel(VoteParams P) {
+    PVNET_SPARE_VGPRS(47);
+    small_stage_prio();
+    // Workgroups go to the 8 XCDs round-robin by linear id; every block of image bi is placed on XCD bi % 8 so that
+    // the two random 16-byte record reads per hypothesis (several per 128-byte line of the image's records) hit
+    // that XCD's L2 after the first touch instead of crossing the fabric once per XCD.
+    const int nbd = (P.hn * P.vn + 255) / 256;               // hypothesis blocks per image
+    const int nb = nbd + 1 + (!LITERAL && P.cull ? P.vn : 0);   // + the plan block + one block per key-point that may be culled
+    const int slot = blockIdx.x >> 3;
+    const int bi = (slot / nb) * 8 + (blockIdx.x & 7);
+    const int blk = slot % nb;
+    if (bi >= P.b) return;
+#ifdef PVNET_K3_PROBE
+    const long long k3_t0 = clock64();
+#else
+    const long long k3_t0 = 0;
+#endif
+    const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
+    const bool live = P.ctrl[bi * CTRL_STRIDE + C_TN0] >= P.min_num && tn > 0;  // gates of :531-534
+    __shared__ KpShared S;
+    const bool kp_origin = !LITERAL && P.mode && P.exact && P.vn <= KP_MAX;   // block-uniform
+    // the thread's own hypothesis: its two records are requested NOW, so that they travel while the origin is worked out
+    const int i = blk * 256 + threadIdx.x;
+    const int hh = i / P.vn, hk = i - hh * P.vn;
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+    if (blk < nbd && live && i < P.hn * P.vn) {
+        int t0, t1;
+        if (P.idxs) {
+            t0 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2];
+            t1 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2 + 1];
+            t0 = t0 < 0 ? 0 : (t0 >= tn ? tn - 1 : t0);  // memory safety only; valid idxs are untouched
+            t1 = t1 < 0 ? 0 : (t1 >= tn ? tn - 1 : t1);
+        } else {
+            const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_HYP, (uint32_t)(P.image_base + bi));
+            t0 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u), (uint32_t)tn);
+            t1 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u + 1u), (uint32_t)tn);
+        }
+        q0 = P.rec[((size_t)bi * P.vn + hk) * P.cap + t0];  // (x, y, direction) of the two pixels
+        q1 = P.rec[((size_t)bi * P.vn + hk) * P.cap + t1];
+    }
+    if (kp_origin) {
+        kp_preamble(P, bi, tn, live, S);
+        if (blk == 0 && (int)threadIdx.x < P.vn) {   // for the scoring kernel's staging (a_rows_exact) and the epilogues
+            const size_t bk = (size_t)bi * P.vn + threadIdx.x;
+            int32_t* o = band_origin_ptr(P, bk);
+            o[0] = S.org[threadIdx.x * 2];
+            o[1] = S.org[threadIdx.x * 2 + 1];
+            *kp_cull_ptr(P, bk) = P.cull ? S.cull[threadIdx.x] : 0;
+        }
+    } else if (!LITERAL && P.mode && P.exact && blk == 0) {   // more than KP_MAX key-points: the image's median pixel for all of them
+        int pm = 0;
+        if (live) pm = P.pix[(size_t)bi * P.cap + tn / 2];
+        for (int kk = threadIdx.x; kk < P.vn; kk += 256) {
+            int32_t* o = band_origin_ptr(P, (size_t)bi * P.vn + kk);
+            o[0] = pm % P.w;
+            o[1] = pm / P.w;
+            *kp_cull_ptr(P, (size_t)bi * P.vn + kk) = 0;
+        }
+    }
+    const bool culling = !LITERAL && P.cull && kp_origin;   // (fill_params: P.cull implies the exact mode and vn <= KP_MAX)
+    if (blk == nbd) {      // one extra block per image plans its scoring work items (consumed by the next launches only)
+        plan_image(P, bi, culling ? S.cull : nullptr);
+        return;
+    }
+    if (blk > nbd) {       // the block of key-point blk - nbd - 1: sorted operands and tile discs, if that key-point is culled
+        __shared__ float2 s_h[CULL_HN];
+        __shared__ uint32_t s_key[CULL_HN];
+        const int k = blk - nbd - 1;
+        if (culling && live && S.cull[k]) cull_block(P, bi, k, tn, S, s_h, s_key, k3_t0);   // (block-uniform)
+        return;
+    }
+    if (i < P.hn * P.vn) {
+    const int h = hh, k = hk;
+    float hx = 0.f, hy = 0.f;
+    if (live) {
+        const float2 d0 = rec_dir(q0), d1 = rec_dir(q1);
+        hyp_intersect(d0.x, d0.y, q0.x, q0.y, d1.x, d1.y, q1.x, q1.y, hx, hy);
+    }
+    P.hyp[((size_t)bi * P.vn + k) * P.hn_pad + h] = make_float2(hx, hy);
+    if (P.atomic_counts) P.counts[((size_t)bi * P.vn + k) * P.hn_pad + h] = 0;  // K4 accumulates into it
+    if (!LITERAL && P.mode && !(culling && S.cull[k])) {  // the same hypothesis about the band origin, as a bf16x3 B operand column
+        float ox = 0.f, oy = 0.f;                         // (a culled key-point's columns are written, in sorted order, by its own block)
+        if (kp_origin) {
+            ox = (float)S.org[k * 2];
+            oy = (float)S.org[k * 2 + 1];
+        } else if (live) {
+            const int pm = P.pix[(size_t)bi * P.cap + tn / 2];  // the origin plan_image() records for this image
+            ox = (float)(pm % P.w);
+            oy = (float)(pm / P.w);
+        }
+        uint4 lo, hi;
+        if (P.exact) b_col_exact(hx - ox, hy - oy, band_rho(tn), P.kband, lo, hi);
+        else b_col(hx - ox, hy - oy, lo, hi);
+        uint4* o = P.hypb + (((size_t)bi * P.vn + k) * P.hn_pad + h) * 2;
+        o[0] = lo;
+        o[1] = hi;
+    }
     }
 }
 
@@ -1335,7 +1314,7 @@ __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
     const ItemRange ir = my_items(P, total);
     for (int item = ir.first; item < ir.end; item += ir.step) {
         const int4 desc = P.items[item];  // (image, key-point, chunk group, hypothesis slice), planned by K3
-        const int bi = desc.x, k = desc.y, cg = desc.z, hq = desc.w;
+        const int bi = desc.x, k = item_kp(desc.y), cg = desc.z, hq = desc.w;
         const int nch = ctrl[bi * CTRL_STRIDE + C_NCHUNKS];
         const int tn = ctrl[bi * CTRL_STRIDE + C_TN];
         const size_t bk = (size_t)bi * P.vn + k;
@@ -1416,7 +1395,13 @@ __global__ __launch_bounds__(256) void score_kernel(VoteParams P) {
 // owns the hypothesis (column = lane & 31, 16 rows per lane), so the vote is cnt += clamp(dt - |cr|) (vote8):
 // 2 VALU operations per test instead of 6, the other four run on the matrix pipe at bf16 rate.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int TILE_U4 = 128;  // uint4 per 32-pixel tile: A_cr rows (32 x 2) then A_dt rows (32 x 2)
+constexpr int TILE_U4 = 128;  // uint4 per 32-pixel tile: four blocks of 32 x 16 bytes -- first operand K slots 0..7 of rows 0..31, its K slots
+                              // 8..15, then the second operand's two halves.  (Round 6: until then a row's two 16-byte halves lay side by
+                              // side, so the 16 lanes that one ds_read_b128 cycle serves -- sixteen rows, ONE half -- used only the even or only
+                              // the odd 16-byte slots of the 256-byte bank row: two-way conflicts on every dense read, four- to five-way on the
+                              // culling kernel's gathered ones.  Now slot = row mod 16: dense reads are conflict-free, gathered ones meet
+                              // sixteen slots instead of eight.)
+static_assert(TILE_U4_ == TILE_U4, "the disc-culling kernel's list addresses (CULL_DEAD, tile = a >> 7, row = a & 31) follow TILE_U4");
 
 // Eight votes of the lane's hypothesis, 1.5 plain VALU operations per test.  The staged rows carry M = 2^k * direction with
 // max(|Mx|, |My|) in [2^60, 2^61) (vote_scale), so any non-zero margin is >= 1 in magnitude and the clamp output modifier turns t = clamp(dt - |cr|) into exactly
@@ -1483,12 +1468,12 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
     const int32_t* __restrict__ ctrl = P.ctrl;
     const int total = ctrl[P.b * CTRL_STRIDE];
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const uint4* lbase = s_t + col * 2 + half;  // this lane's 16 bytes of every A row block
+    const uint4* lbase = s_t + half * 32 + col;  // this lane's 16 bytes of every A row block (tile layout: TILE_U4)
 
     const ItemRange ir = my_items(P, total);
     for (int item = ir.first; item < ir.end; item += ir.step) {
         const int4 desc = P.items[item];  // (image, key-point, chunk group, hypothesis slice), planned by K3
-        const int bi = desc.x, k = desc.y, cg = desc.z, hq = desc.w;
+        const int bi = desc.x, k = item_kp(desc.y), cg = desc.z, hq = desc.w;
         const int tn = ctrl[bi * CTRL_STRIDE + C_TN];
         const float ox = (float)ctrl[bi * CTRL_STRIDE + C_OX], oy = (float)ctrl[bi * CTRL_STRIDE + C_OY];
         const size_t bk = (size_t)bi * P.vn + k;
@@ -1509,9 +1494,9 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(VoteParams P) {
             float4 a;
             float2 b;
             make_pixrec(q, P.tau, ox, oy, a, b);  // a = (My, -Mx, -Ec, Tx), b = (Ty, -Ed); zero record -> zero rows
-            uint4* t = s_t + (i >> 5) * TILE_U4 + (i & 31) * 2;
-            a_row(a.x, a.y, a.z, t[0], t[1]);
-            a_row(a.w, b.x, b.y, t[64], t[65]);
+            uint4* t = s_t + (i >> 5) * TILE_U4 + (i & 31);
+            a_row(a.x, a.y, a.z, t[0], t[32]);
+            a_row(a.w, b.x, b.y, t[64], t[96]);
         }
         lds_barrier();
 
@@ -1730,7 +1715,7 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
     const int32_t* __restrict__ ctrl = P.ctrl;
     const int total = ctrl[P.b * CTRL_STRIDE];
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const uint4* lbase = s_t + col * 2 + half;
+    const uint4* lbase = s_t + half * 32 + col;
 
     // TIMED only: shader-clock cycles of this workgroup's wave 0 per phase (0 staging incl. the wait for its loads and the
     // barrier, 1 scoring loop, 2 count flush + cell list + barrier, 3 re-evaluation + the next item's first barrier)
@@ -1773,7 +1758,8 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
     const ItemRange ir = my_items<RUNS>(P, total);
     for (int item = ir.first; item < ir.end; item += ir.step) {
         const int4 desc = P.items[item];
-        const int bi = desc.x, k = desc.y, cg = desc.z, hq = desc.w;
+        if (item_culled(desc.y)) continue;   // (workgroup-uniform) a key-point the disc-culling kernel scores: that launch takes the item
+        const int bi = desc.x, k = item_kp(desc.y), cg = desc.z, hq = desc.w;
         const int tn = ctrl[bi * CTRL_STRIDE + C_TN];
         const float rho = band_rho(tn);
         const size_t bk = (size_t)bi * P.vn + k;
@@ -1815,14 +1801,14 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
             float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p < tpad) q = P.rec[bk * P.cap + p];
             s_raw[i] = q;
-            uint4* t = s_t + (i >> 5) * TILE_U4 + (i & 31) * 2;
+            uint4* t = s_t + (i >> 5) * TILE_U4 + (i & 31);
             uint4 r0, r1, r2, r3;  // (in registers first: by reference into LDS every assignment inside would be a store)
             float mu_unused;
             a_rows_exact(q, P.tau, ox, oy, rho, r0, r1, r2, r3, mu_unused);
             t[0] = r0;
-            t[1] = r1;
+            t[32] = r1;
             t[64] = r2;
-            t[65] = r3;
+            t[96] = r3;
         }
         if (fresh) {
 #pragma unroll
@@ -2048,7 +2034,7 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
     const int32_t* __restrict__ ctrl = P.ctrl;
     const int total = ctrl[P.b * CTRL_STRIDE];
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const uint4* lbase = s_t + col * 2 + half;
+    const uint4* lbase = s_t + half * 32 + col;
     const int ntl = P.hn_pad >> 5;
 
     unsigned long long ph[4] = {0ull, 0ull, 0ull, 0ull}, tprev = 0ull;
@@ -2088,7 +2074,8 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
     const ItemRange ir = my_items<RUNS>(P, total);
     for (int item = ir.first; item < ir.end; item += ir.step) {
         const int4 desc = P.items[item];
-        const int bi = desc.x, k = desc.y, cg = desc.z, hq = desc.w;
+        if (!item_culled(desc.y)) continue;   // (workgroup-uniform) a key-point the full exact kernel scores
+        const int bi = desc.x, k = item_kp(desc.y), cg = desc.z, hq = desc.w;
         const int tn = ctrl[bi * CTRL_STRIDE + C_TN];
         const float rho = band_rho(tn);
         const size_t bk = (size_t)bi * P.vn + k;
@@ -2131,20 +2118,20 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
             float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p < tpad) q = P.rec[bk * P.cap + p];
             s_raw[i] = q;
-            uint4* t = s_t + (i >> 5) * TILE_U4 + (i & 31) * 2;
+            uint4* t = s_t + (i >> 5) * TILE_U4 + (i & 31);
             uint4 r0, r1, r2, r3;
             float mu;
             a_rows_exact(q, P.tau, ox, oy, rho, r0, r1, r2, r3, mu);
             t[0] = r0;
-            t[1] = r1;
+            t[32] = r1;
             t[64] = r2;
-            t[65] = r3;
+            t[96] = r3;
             s_sig[i] = 1.f - mu;
             if (i == 0) {   // the dead row the lists are padded with: dt' = -4, cr' = 0 -- no vote, no flag
                 s_t[CULL_DEAD] = make_uint4(0u, 0u, 0u, 0u);
-                s_t[CULL_DEAD + 1] = make_uint4(0u, 0u, 0u, pk(0u, 0xC080u));
+                s_t[CULL_DEAD + 32] = make_uint4(0u, 0u, 0u, pk(0u, 0xC080u));
                 s_t[CULL_DEAD + 64] = make_uint4(0u, 0u, 0u, 0u);
-                s_t[CULL_DEAD + 65] = make_uint4(0u, 0u, 0u, 0u);
+                s_t[CULL_DEAD + 96] = make_uint4(0u, 0u, 0u, 0u);
             }
         }
         lds_barrier();
@@ -2186,7 +2173,7 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
                 while (um) {
                     const int r = __ffs((int)um) - 1;
                     um &= um - 1u;
-                    dst[at++] = (uint16_t)(pt * TILE_U4 + ((r >> 2) * 8 + half * 4 + (r & 3)) * 2);   // uint4 index of the pixel's dt' row
+                    dst[at++] = (uint16_t)(pt * TILE_U4 + (r >> 2) * 8 + half * 4 + (r & 3));   // uint4 index of the first 16 bytes of the pixel's dt' row
                 }
             }
         }
@@ -2219,13 +2206,13 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
                 // previous group's last 15 vote operations fill the wait for this group's MFMAs, as in the exact kernel.
                 const uint16_t* const lst = s_list + j * CULL_NPX + col;
                 const unsigned a0 = lst[0];
-                uint4 Ra = s_t[a0 + half], Rb = s_t[a0 + half + 64];
+                uint4 Ra = s_t[a0 + half * 32], Rb = s_t[a0 + half * 32 + 64];
                 unsigned an = lst[ng > 1 ? 32 : 0];
                 {
                     const f32x16 va = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Ra), B[t], zero, 0, 0, 0);
                     const f32x16 vb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Rb), B[t], zero, 0, 0, 0);
-                    Ra = s_t[an + half];
-                    Rb = s_t[an + half + 64];
+                    Ra = s_t[an + half * 32];
+                    Rb = s_t[an + half * 32 + 64];
                     an = lst[(ng > 2 ? 2 : ng - 1) * 32];
                     __builtin_amdgcn_sched_barrier(0);
                     asm volatile("s_nop 11");   // (the votes are inline asm: the wait states are ours, tools/check_mfma_hazard.py)
@@ -2237,8 +2224,8 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
                 for (int g = 1; g < ng; ++g) {
                     const f32x16 va = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Ra), B[t], zero, 0, 0, 0);
                     const f32x16 vb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Rb), B[t], zero, 0, 0, 0);
-                    Ra = s_t[an + half];        // (the last trip re-reads the last group: harmless)
-                    Rb = s_t[an + half + 64];
+                    Ra = s_t[an + half * 32];        // (the last trip re-reads the last group: harmless)
+                    Rb = s_t[an + half * 32 + 64];
                     an = lst[(g + 2 < ng ? g + 2 : ng - 1) * 32];
                     __builtin_amdgcn_sched_barrier(0);
                     vote_slow_close(cnt[t], flg[t], acc, dmo, PV_XS);   // the previous group's last 15 operations fill the wait
@@ -2299,7 +2286,7 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
                     const int slot = (ng - 1 - gb) * 32 + row;
                     if (slot < nu) {   // (beyond: the dead row)
                         const unsigned a = s_list[j * CULL_NPX + slot];
-                        const float4 r = s_raw[(a >> 7) * 32 + ((a & 127u) >> 1)];
+                        const float4 r = s_raw[(a >> 7) * 32 + (a & 31u)];
                         votes += inlier_literal(r.x, r.y, r.z, r.w, hv.x, hv.y, P.thresh) ? 1 : 0;
                         ++ntests;
                     }
@@ -2374,22 +2361,23 @@ __global__ __launch_bounds__(256) void band_margin_kernel(VoteParams P, unsigned
         uint4 r0, r1, r2, r3;
         float mu_unused;
         a_rows_exact(q, P.tau, ox, oy, rho, r0, r1, r2, r3, mu_unused);
-        uint4* t = s_t + (i >> 5) * TILE_U4 + (i & 31) * 2;
+        uint4* t = s_t + (i >> 5) * TILE_U4 + (i & 31);
         t[0] = r0;
-        t[1] = r1;
+        t[32] = r1;
         t[64] = r2;
-        t[65] = r3;
+        t[96] = r3;
     }
     __syncthreads();
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const uint4* lbase = s_t + col * 2 + half;
+    const uint4* lbase = s_t + half * 32 + col;
     const int left = (tpad - grp * 256 + 31) >> 5, nti = left < 8 ? left : 8;
     float worst = 0.f;
     unsigned ndis = 0u, nband = 0u, ntest = 0u;
-    for (int ht = wave; ht * 32 < (P.cull ? P.hn_pad : P.hn); ht += 4) {     // hypothesis tiles of this wave
+    const bool culled = P.cull && *kp_cull_ptr(P, bk) != 0;   // this key-point's operands are in Hilbert order
+    for (int ht = wave; ht * 32 < (culled ? P.hn_pad : P.hn); ht += 4) {     // hypothesis tiles of this wave
         const int h = ht * 32 + col;
         const bf16x8 Bc = __builtin_bit_cast(bf16x8, P.hypb[(bk * P.hn_pad + h) * 2 + half]);
-        const float2 hv = (P.cull ? P.hyps : P.hyp)[bk * P.hn_pad + h];   // (disc culling: hypb is in Hilbert order, and so is hyps)
+        const float2 hv = (culled ? P.hyps : P.hyp)[bk * P.hn_pad + h];   // (disc culling: hypb is in Hilbert order, and so is hyps)
         for (int tile = 0; tile < nti; ++tile) {
             const bf16x8 Ad = __builtin_bit_cast(bf16x8, lbase[tile * TILE_U4]);
             const bf16x8 Ac = __builtin_bit_cast(bf16x8, lbase[tile * TILE_U4 + 64]);
@@ -2399,7 +2387,7 @@ __global__ __launch_bounds__(256) void band_margin_kernel(VoteParams P, unsigned
             for (int r = 0; r < 16; ++r) {
                 const int row = (r >> 2) * 8 + half * 4 + (r & 3);
                 const int p = grp * 256 + tile * 32 + row;
-                if (p >= tn || (P.cull ? P.perm[bk * P.hn_pad + h] >= P.hn : h >= P.hn)) continue;    // padding rows / columns: nobody reads their counts
+                if (p >= tn || (culled ? P.perm[bk * P.hn_pad + h] >= P.hn : h >= P.hn)) continue;    // padding rows / columns: nobody reads their counts
                 const float x = vd[r] - fabsf(vc[r]);  // (one IEEE subtraction, as v_sub_f32 x, d, |c|)
                 const float4 q = s_raw[tile * 32 + row];
                 const bool lit = inlier_literal(q.x, q.y, q.z, q.w, hv.x, hv.y, P.thresh);
@@ -2479,8 +2467,8 @@ __global__ __launch_bounds__(RT) void select_refine_kernel(VoteParams P) {
     // (one 32-bit load per chunk row) with eight loads in flight: the rows are latency-, not bandwidth-bound.
     unsigned long long best = 0;
     const size_t row = (size_t)(P.hn_pad >> 1);  // hn_pad is even
-    if (!LITERAL && P.cull) {  // disc culling: K4 counted in Hilbert order -- back to the caller's order (what every reader of
-                               // `counts` expects), the first CALLER index winning ties as before
+    if (!LITERAL && P.cull && *kp_cull_ptr(P, bk) != 0) {  // a disc-culled key-point: K4 counted in Hilbert order -- back to the caller's
+                                                           // order (what every reader of `counts` expects), the first CALLER index winning ties
         for (int p = threadIdx.x; p < P.hn_pad; p += RT) {
             const int h = P.perm[bk * P.hn_pad + p];
             if (h >= P.hn) continue;   // padding
@@ -2925,7 +2913,7 @@ int layout_fingerprint(const PvnetVoteLayout& L) {
     uint64_t x = 0x9E3779B97F4A7C15ull;
     const uint64_t v[] = {(uint64_t)L.chunk, (uint64_t)L.hpl, (uint64_t)L.wg_g, (uint64_t)L.reserved_, (uint64_t)L.cap,
                           (uint64_t)L.hn_pad, (uint64_t)L.off_rec, (uint64_t)L.off_hyp, (uint64_t)L.off_counts,
-                          (uint64_t)L.off_win, (uint64_t)L.total_bytes, (uint64_t)L.cull, (uint64_t)L.off_perm};
+                          (uint64_t)L.off_win, (uint64_t)L.total_bytes, (uint64_t)L.cull, (uint64_t)L.off_perm, (uint64_t)L.off_hypc};
     for (uint64_t e : v) { x ^= e + 0x9E3779B97F4A7C15ull + (x << 6) + (x >> 2); }
     const int fp = (int)(x ^ (x >> 32));
     return fp ? fp : 1;
@@ -2959,10 +2947,12 @@ struct Tuning {
     int score_runs;     // PVNET_SCORE_RUNS        exact mode, 8 tiles per wave: 1 = contiguous item runs per workgroup (B columns, hypotheses and
                         //                         vote counters kept while the (image, key-point) stays), 0 = strided items;
                         //                         -1 (default): runs for calls flagged PVNET_F_CONCURRENT
-    int score_cull;     // PVNET_SCORE_CULL        exact mode, 8 tiles per wave, 256-pixel items, hn_pad <= 4096: 1 = disc culling
-                        //                         (hypotheses sorted along a Hilbert curve, per-pixel certainty against every tile's
-                        //                         disc, uncertain pixels gathered: score_exact_kernel_cull), 0 = the full kernel;
-                        //                         -1 (default): PVNET_CULL_DEFAULT
+    int score_cull;     // PVNET_SCORE_CULL        exact mode, 8 tiles per wave, 256-pixel items, hn_pad = 1024: disc culling (hypotheses
+                        //                         sorted along a Hilbert curve, per-pixel certainty against every tile's disc, uncertain
+                        //                         pixels gathered: score_exact_kernel_cull) of 2 = the key-points K3 selects from the
+                        //                         spread of their candidate intersections (the default: PVNET_CULL_DEFAULT), 1 = every
+                        //                         key-point (tests, probes), 0 = none (the layout then has no culling buffers)
+    int cull_q_milli;   // PVNET_CULL_Q_MILLI      the selection threshold of 2, in thousandths (kp_preamble; profiles/r06_cull_crossover.txt)
     int exact_fold;     // PVNET_EXACT_FOLD        exact mode: -1 (default) = by threshold, 0 = one cell per work item and
                         //                         hypothesis, 1 = one cell per pixel tile (band_fold1())
     int dev_stages;     // PVNET_DEV_STAGES        development aid: bit mask of the stages to launch
@@ -2981,6 +2971,7 @@ void load_tuning(Tuning& t) {
     t.exact_fold = env_int("PVNET_EXACT_FOLD", -1);
     t.score_runs = env_int("PVNET_SCORE_RUNS", -1);
     t.score_cull = env_int("PVNET_SCORE_CULL", -1);
+    t.cull_q_milli = env_int("PVNET_CULL_Q_MILLI", PVNET_CULL_Q_MILLI);
     t.dev_stages = env_int("PVNET_DEV_STAGES", 0x3F);
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -3075,13 +3066,9 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
     }
     PV_HIP(mark(3));
     if (stages & 8) {   // K3
-        dim3 grid((unsigned)(((P.hn * P.vn + 255) / 256 + 1) * ((P.b + 7) / 8) * 8));
-        if (P.cull) {   // one workgroup per (image, key-point): hypotheses, Hilbert sort, tile discs (+ one plan block per image)
-            int n2 = CULL_K3_THREADS;
-            while (n2 < P.hn_pad) n2 <<= 1;
-            const size_t lds = (size_t)P.hn_pad * sizeof(float2) + (size_t)n2 * sizeof(uint32_t);
-            hipLaunchKernelGGL(hypothesis_cull_kernel, dim3((unsigned)((P.vn + 1) * ((P.b + 7) / 8) * 8)), dim3(CULL_K3_THREADS), lds, s, P);
-        } else if (literal) hipLaunchKernelGGL(hypothesis_kernel<true>, grid, dim3(256), 0, s, P);
+        // per image: the hypothesis blocks, the plan block and -- where key-points may be disc-culled -- one block per key-point
+        dim3 grid((unsigned)(((P.hn * P.vn + 255) / 256 + 1 + (!literal && P.cull ? P.vn : 0)) * ((P.b + 7) / 8) * 8));
+        if (literal) hipLaunchKernelGGL(hypothesis_kernel<true>, grid, dim3(256), 0, s, P);
         else hipLaunchKernelGGL(hypothesis_kernel<false>, grid, dim3(256), 0, s, P);
         PV_LAUNCH_CHECK();
     }
@@ -3096,21 +3083,8 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
         if (wgs > max_items) wgs = max_items;
         if (wgs < 1) wgs = 1;
         if (score_grid) *score_grid = (int)wgs;
-        if (P.cull) {
-            const bool conc = (P.flags & PVNET_F_CONCURRENT) != 0;
-            const bool runs = T.score_runs == 1 || (T.score_runs < 0 && conc);
-            long long w2 = T.wgs_per_cu >= 0 ? wgs : (long long)T.cus * 9;   // three resident workgroups per CU (48 KB of LDS each): three rounds
-            if (w2 > max_items) w2 = max_items;
-            if (w2 < 1) w2 = 1;
-            if (score_grid) *score_grid = (int)w2;
-            const dim3 g((unsigned)w2), t(256);
-            if (timed_score) {
-                if (runs) hipLaunchKernelGGL(score_exact_kernel_cull_1_1, g, t, CULL_LDS_BYTES, s, P);
-                else hipLaunchKernelGGL(score_exact_kernel_cull_1_0, g, t, CULL_LDS_BYTES, s, P);
-            } else {
-                if (runs) hipLaunchKernelGGL(score_exact_kernel_cull_0_1, g, t, CULL_LDS_BYTES, s, P);
-                else hipLaunchKernelGGL(score_exact_kernel_cull_0_0, g, t, CULL_LDS_BYTES, s, P);
-            }
+        if (P.exact && P.cull == 1) {
+            // every key-point is disc-culled (PVNET_SCORE_CULL=1): no item is left for the full kernel
         } else if (P.exact) {
             const int mh = P.wg_g * P.hpl / 2;
             const int npx = P.wg_s * P.chunk;
@@ -3174,6 +3148,24 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
         } else {
             int rc = literal ? launch_score<true>(P, dim3((unsigned)wgs), s) : launch_score<false>(P, dim3((unsigned)wgs), s);
             if (rc) return rc;
+        }
+        PV_LAUNCH_CHECK();
+        if (P.cull) {   // the key-points K3 marked (all of them: P.cull = 1): items carry the mark, the kernel skips the others
+            const bool conc = (P.flags & PVNET_F_CONCURRENT) != 0;
+            const bool runs = T.score_runs == 1 || (T.score_runs < 0 && conc);
+            long long w2 = T.wgs_per_cu >= 0 ? wgs : (long long)T.cus * 9;   // three resident workgroups per CU (48 KB of LDS each): three rounds
+            if (w2 > max_items) w2 = max_items;
+            if (w2 < 1) w2 = 1;
+            const bool timed_cull = timed_score && P.cull == 1;   // (the device-clock stamps of a timed launch belong to ONE kernel)
+            if (score_grid && P.cull == 1) *score_grid = (int)w2;
+            const dim3 g((unsigned)w2), t(256);
+            if (timed_cull) {
+                if (runs) hipLaunchKernelGGL(score_exact_kernel_cull_1_1, g, t, CULL_LDS_BYTES, s, P);
+                else hipLaunchKernelGGL(score_exact_kernel_cull_1_0, g, t, CULL_LDS_BYTES, s, P);
+            } else {
+                if (runs) hipLaunchKernelGGL(score_exact_kernel_cull_0_1, g, t, CULL_LDS_BYTES, s, P);
+                else hipLaunchKernelGGL(score_exact_kernel_cull_0_0, g, t, CULL_LDS_BYTES, s, P);
+            }
         }
         PV_LAUNCH_CHECK();
     }
@@ -3251,8 +3243,11 @@ int fill_params(VoteParams& P, const void* mask, int mask_dtype, const int64_t* 
     P.counts = reinterpret_cast<int32_t*>(base + L.off_counts);
     P.win = reinterpret_cast<int32_t*>(base + L.off_win);
     P.out = out; P.status = status;
-    // disc culling: the layout has its buffers, the call runs the exact mode with cells of one pixel tile
-    P.cull = (L.cull && P.exact && P.fold1) ? 1 : 0;
+    // disc culling: the layout has its buffers, the call runs the exact mode with cells of one pixel tile; every key-point
+    // (PVNET_SCORE_CULL=1) or the ones K3 selects (2: the default)
+    const int cull_knob = tuning().score_cull >= 0 ? tuning().score_cull : PVNET_CULL_DEFAULT;
+    P.cull = (L.cull && P.exact && P.fold1 && vn <= KP_MAX) ? (cull_knob == 1 ? 1 : 2) : 0;
+    P.cull_q = 1e-3f * (float)tuning().cull_q_milli;
     P.perm = reinterpret_cast<int32_t*>(base + L.off_perm);
     P.hyps = reinterpret_cast<float2*>(base + L.off_hyps);
     P.cnts = reinterpret_cast<int32_t*>(base + L.off_cnts);
@@ -3298,9 +3293,10 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
 
     const long long units = (long long)b * vn * hgroups;
     int chunk = units >= 128 ? 128 : 64;
-    // disc culling works on 256-pixel items (two chunks of 128): where it applies, small batches keep that shape too
+    // disc culling works on 256-pixel items (two chunks of 128); PVNET_SCORE_CULL=1 (every key-point culled: tests, probes) gives
+    // small batches that shape too, the default (2: K3 selects) leaves their layout alone
     const int cull_knob = T.score_cull >= 0 ? T.score_cull : PVNET_CULL_DEFAULT;
-    if (cull_knob && mode && T.score_atomic && wg_g * hpl / 2 == 8 && hgroups * 64 * hpl <= CULL_MAX_HN) chunk = CULL_NPX / (4 / wg_g);
+    if (cull_knob == 1 && mode && T.score_atomic && wg_g * hpl / 2 == 8 && hgroups * 64 * hpl == CULL_HN) chunk = CULL_NPX / (4 / wg_g);
     if (T.chunk >= 0) chunk = T.chunk;
     if (chunk < PAD || chunk % PAD != 0 || chunk > 1024) return PVNET_E_UNSUPPORTED;  // LDS: 4 * 1024 * 32 B
     if (mode && chunk % 32 != 0) return PVNET_E_UNSUPPORTED;  // whole 32-pixel MFMA tiles
@@ -3320,8 +3316,9 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     L->nseg = (L->words + SEG_WORDS - 1) / SEG_WORDS;
-    // ctrl rows [b + 1][8], then the exact mode's band origins int32 [b][vn][2] (band_origin_ptr())
-    L->off_ctrl = take(sizeof(int32_t) * (CTRL_STRIDE * (size_t)(b + 1) + 2 * (size_t)b * vn));
+    // ctrl rows [b + 1][8], then the exact mode's band origins int32 [b][vn][2] (band_origin_ptr()), then which key-points are
+    // disc-culled int32 [b][vn] (kp_cull_ptr())
+    L->off_ctrl = take(sizeof(int32_t) * (CTRL_STRIDE * (size_t)(b + 1) + 3 * (size_t)b * vn));
     // [2][b][nseg] int32 (the second array holds the mask's segment counts; the first is unused since round 2), then,
     // when thinning is possible (max_num < h*w), the segments' cumulative histograms uint16 [b][nseg][THIN_BINS]
     L->off_seg = take(align_up(sizeof(int32_t) * 2 * (size_t)b * L->nseg, 16) +
@@ -3337,8 +3334,9 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     L->off_partial = take(T.score_atomic ? 0 : sizeof(uint16_t) * (size_t)b * vn * L->max_chunks * L->hn_pad);
     L->off_counts = take(sizeof(int32_t) * (size_t)b * vn * L->hn_pad);
     L->off_win = take(sizeof(int32_t) * 2 * (size_t)b * vn);
-    // disc culling (exact mode): 8 hypothesis tiles per wave, 256-pixel work items, a key-point's hypotheses sortable in LDS
-    L->cull = (cull_knob && mode && T.score_atomic && wg_g * hpl / 2 == 8 && L->wg_s * chunk == CULL_NPX && L->hn_pad <= CULL_MAX_HN) ? 1 : 0;
+    // disc culling (exact mode): 8 hypothesis tiles per wave, 256-pixel work items, one slice of 1 024 hypotheses per key-point (four
+    // sort keys per thread of a K3 block), at most KP_MAX key-points (the origin estimate's arrays)
+    L->cull = (cull_knob && mode && T.score_atomic && wg_g * hpl / 2 == 8 && L->wg_s * chunk == CULL_NPX && L->hn_pad == CULL_HN && vn <= KP_MAX) ? 1 : 0;
     L->off_perm = take(L->cull ? sizeof(int32_t) * (size_t)b * vn * L->hn_pad : 0);
     L->off_hyps = take(L->cull ? sizeof(float) * 2 * (size_t)b * vn * L->hn_pad : 0);
     L->off_cnts = take(L->cull ? sizeof(int32_t) * (size_t)b * vn * L->hn_pad : 0);

@@ -40,6 +40,8 @@ def load_pnp_library() -> C.CDLL:
         lib.pvnet_pnp_solve.argtypes = [dp] * 5 + [C.c_int]
         lib.pvnet_pnp_solve_batch.restype = C.c_int
         lib.pvnet_pnp_solve_batch.argtypes = [dp] * 5 + [C.c_int, C.c_int]
+        lib.pvnet_pnp_poses_from_rt.restype = None
+        lib.pvnet_pnp_poses_from_rt.argtypes = [dp, dp, C.c_int]
         lib.pvnet_angle_axis_to_matrix.restype = None
         lib.pvnet_angle_axis_to_matrix.argtypes = [dp, dp]
         lib.pvnet_matrix_to_angle_axis.restype = None
@@ -222,7 +224,9 @@ def pnp_batch(points_3d, points_2d, camera_matrix, weights_2d=None):
                                                   _dptr(out), n, pn)
     if rc < 0:
         raise RuntimeError("pvnet_pnp_solve_batch: bad arguments (needs >= 6 points per image)")
-    return np.stack([np.concatenate([rodrigues(o[:3]), o[3:, None]], 1) if np.any(o) else np.zeros((3, 4)) for o in out])
+    poses = np.empty((n, 3, 4), np.float64)   # (R | t) per image, zeros where the solve failed: converted natively too (a numpy
+    load_pnp_library().pvnet_pnp_poses_from_rt(_dptr(out), _dptr(poses), n)   # loop over 32 poses cost more than solving them)
+    return poses
 
 
 # ---- metrics of Evaluator (evaluation_utils.py:75-134) -----------------------------------------------------

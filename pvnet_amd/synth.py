@@ -60,7 +60,7 @@ def add_noise(planar: np.ndarray, fg: np.ndarray, rng, sigma_rad=0.05, outlier_f
 
 
 def make_image(index: int, h=480, w=640, vn=9, radius=40, background="zeros", noise=False,
-               mask_dtype=np.int64, seed_base=20240):
+               mask_dtype=np.int64, seed_base=20240, noise_sigma=0.05, outlier_frac=0.10):
     """One synthetic image as SURVEY.md section 8(d) specifies.  Returns (mask [h,w], planar [2vn,h,w], kpts [vn,2])."""
     rng = np.random.default_rng(seed_base + index)
     mx = min(100, w // 4)
@@ -72,7 +72,7 @@ def make_image(index: int, h=480, w=640, vn=9, radius=40, background="zeros", no
                      rng.uniform(cy - 1.5 * radius, cy + 1.5 * radius, vn)], axis=1)
     planar = field_from_keypoints(fg, kpts, background, rng)
     if noise:
-        planar = add_noise(planar, fg, rng)
+        planar = add_noise(planar, fg, rng, sigma_rad=noise_sigma, outlier_frac=outlier_frac)   # (defaults: SURVEY.md 8d's noise variant)
     return fg.astype(mask_dtype), planar, kpts
 
 

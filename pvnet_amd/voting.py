@@ -102,7 +102,7 @@ def load_library() -> C.CDLL:
     lib.pvnet_vote_band_margin.argtypes = [C.c_float, C.c_void_p] + ws_tail
     lib.pvnet_vote_tuning_reload.restype = None
     lib.pvnet_vote_tuning_reload.argtypes = []
-    if lib.pvnet_vote_abi_version() != 8:
+    if lib.pvnet_vote_abi_version() != 9:
         raise RuntimeError("pvnet_amd: libpvnet_vote.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib
@@ -185,6 +185,8 @@ def _debug_views(ws: torch.Tensor, L: Layout):
         win=view(L.off_win, 8 * b * vn, torch.int32, (b, vn, 2)),
         # exact mode: the origin of the rounding band per (image, key-point), behind the ctrl rows (band_origin_ptr())
         band_origin=view(L.off_ctrl + 4 * 8 * (b + 1), 8 * b * vn, torch.int32, (b, vn, 2)),
+        # which (image, key-point)s the disc-culling kernel scored (kp_cull_ptr(); written by exact-mode calls only)
+        cull_bits=view(L.off_ctrl + 4 * 8 * (b + 1) + 8 * b * vn, 4 * b * vn, torch.int32, (b, vn)),
     )
 
 
@@ -337,7 +339,13 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
         # what the library really ran: without the matrix-pipe buffers (PVNET_SCORE_MODE=0) the default mode is scored literally
         d["mode"] = "literal" if (literal or (not approx and not L.reserved_)) else ("approx" if approx else "exact")
         d["concurrent"] = bool(flags & F_CONCURRENT)
-        d["cull"] = bool(L.cull) and d["mode"] == "exact"   # (and cells of one pixel tile: PVNET_EXACT_FOLD != 0)
+        # disc culling is decided on the device per (image, key-point): d["cull_bits"] is what the library recorded (not
+        # re-derived from the layout); d["cull"] = any key-point culled.  Reading it synchronises -- debug only.
+        if d["mode"] == "exact" and L.cull:
+            d["cull"] = bool(d["cull_bits"].any().item())
+        else:
+            d["cull"] = False
+            d["cull_bits"] = torch.zeros((b, vn), dtype=torch.int32, device=dev)
         if band_stats:  # (cells re-evaluated, literal tests made) of this call; synchronises
             d["band_stats"] = tuple(int(x) for x in d["ctrl"][b, 4:6].tolist())
             # disc culling: (fine steps executed, steps the full exact kernel would have executed); (0, 0) when the call did not cull

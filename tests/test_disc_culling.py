@@ -1,5 +1,6 @@
-"""GPU tests of the exact mode's DISC CULLING (round 5; PVNET_SCORE_CULL=1, pvnet_vote.hip: hypothesis_cull_kernel /
-score_exact_kernel_cull): each key-point's hypotheses are sorted along a Hilbert curve, every tile of 32 is described by a disc,
+"""GPU tests of the exact mode's DISC CULLING (rounds 5-6; pvnet_vote.hip: cull_block of hypothesis_kernel / score_exact_kernel_cull;
+PVNET_SCORE_CULL=1 culls every key-point, the default lets K3 select them per (image, key-point) from the spread of the band-origin
+candidates): a culled key-point's hypotheses are sorted along a Hilbert curve, every tile of 32 is described by a disc,
 and a pixel whose margin at the disc's centre exceeds the disc's radius (+ the rounding band) votes for all 32 hypotheses of the
 tile or for none -- only the other pixels are gathered into MFMA tiles.  The claim under test: EVERY inlier count, every winner
 and every key-point is the one the full exact kernel (and therefore literal mode, i.e. the reference's own arithmetic:
@@ -28,9 +29,13 @@ def batch(n, first, h, w, radius, noise=True, background="normal", **kw):
 
 @pytest.fixture
 def cull(monkeypatch):
-    """the culling layout for the calls of one test; the library default comes back afterwards"""
+    """every key-point culled (True) / none (False) / the library's own selection ("auto") for the calls of one test; the library
+    default (auto) comes back afterwards"""
     def on(flag=True):
-        monkeypatch.setenv("PVNET_SCORE_CULL", "1" if flag else "0")
+        if flag == "auto":
+            monkeypatch.delenv("PVNET_SCORE_CULL", raising=False)
+        else:
+            monkeypatch.setenv("PVNET_SCORE_CULL", "1" if flag else "0")
         voting.reload_tuning()
     yield on
     monkeypatch.delenv("PVNET_SCORE_CULL", raising=False)
@@ -51,7 +56,7 @@ def test_culled_counts_equal_literal_and_full_kernel_at_the_bench_shape(cull, th
     cull(True)
     out, d = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=thresh, seed=3, return_debug=True, concurrent=conc,
                                            band_stats=True)
-    assert d["cull"] and d["layout"].cull == 1 and d["mode"] == "exact"
+    assert d["cull"] and bool(d["cull_bits"].all()) and d["layout"].cull == 1 and d["mode"] == "exact"
     assert d["hyp"].cpu().numpy().tobytes() == lit[3].cpu().numpy().tobytes()   # caller order, the same draws
     assert torch.equal(d["counts"], lit[1]) and torch.equal(d["counts"], full[1])
     assert torch.equal(d["win"], lit[2]) and torch.equal(d["win"], full[2])
@@ -93,15 +98,15 @@ def test_clean_field_is_almost_entirely_certain(cull):
     assert torch.equal(d["counts"], dl["counts"])
 
 
-@pytest.mark.parametrize("hn,b", [(777, 3), (1024, 1), (2048, 2), (1500, 2), (4096, 1)])
-def test_padding_hypotheses_several_slices_and_the_sort_limit(cull, hn, b):
-    """hn = 777 / 1500: padding columns inside the last tile and whole padding tiles; 2048 / 4096: two / four hypothesis slices
-    per key-point, each with its own 32 tile centres; 4096 is the largest count the sort handles (beyond: the full kernel)"""
+@pytest.mark.parametrize("hn,b", [(777, 3), (1024, 1), (1000, 2), (1023, 32), (769, 1)])
+def test_padding_hypotheses_and_small_batches(cull, hn, b):
+    """hn < 1024: padding columns inside the last tile and whole padding tiles (they sort behind every real hypothesis and are
+    never scored); b = 1: PVNET_SCORE_CULL=1 gives a small batch 256-pixel items too"""
     m, v, _ = batch(b, 80 + hn, 240, 320, 30)
     lit = snapshot(*voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=0.99, seed=5, literal=True, return_debug=True))
     cull(True)
     out, d = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=0.99, seed=5, return_debug=True)
-    assert d["cull"]
+    assert d["cull"] and bool(d["cull_bits"].all())
     assert torch.equal(d["counts"], lit[1]) and torch.equal(d["win"], lit[2])
     assert d["hyp"].cpu().numpy().tobytes() == lit[3].cpu().numpy().tobytes()
     assert float((out - lit[0]).abs().max()) < 1e-3
@@ -110,7 +115,7 @@ def test_padding_hypotheses_several_slices_and_the_sort_limit(cull, hn, b):
 def test_layouts_the_culling_kernel_does_not_cover_run_the_full_kernel(cull):
     cull(True)
     m, v, _ = batch(2, 90, 240, 320, 24)
-    for hn in (256, 8192):   # 2 hypothesis tiles per wave / more hypotheses than the sort holds in LDS
+    for hn in (256, 2048, 8192):   # 2 hypothesis tiles per wave / more than the one slice of 1 024 hypotheses a K3 block sorts
         _, lit = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=0.99, seed=6, literal=True, return_debug=True)
         cl = lit["counts"].clone()
         _, d = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=0.99, seed=6, return_debug=True)
@@ -168,3 +173,35 @@ def test_siblings_read_caller_order_counts_and_the_band_margin_still_holds(cull)
     _, d = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=4, return_debug=True)
     bm = voting.band_margin(d, 0.99)
     assert bm["tests"] > 1e7 and bm["worst"] < 0.5
+
+
+def test_the_library_selects_clean_key_points_and_leaves_noisy_ones_to_the_full_kernel(cull):
+    """the default: K3 decides per (image, key-point) from the spread of the band-origin candidates -- a clean field's key-points are
+    culled, the noisy benchmark field's are not, and a batch that holds both gets both kernels in one call; every count equals
+    literal mode's either way"""
+    cull("auto")
+    mc, vc, _ = batch(32, 300, 480, 640, 40, noise=False, background="zeros")
+    _, d = voting.ransac_voting_layer_v3(mc, vc, 1024, inlier_thresh=0.99, seed=1, return_debug=True, band_stats=True)
+    assert d["layout"].cull == 1 and bool(d["cull_bits"].all())
+    ex, total = d["cull_stats"]
+    assert total > 0 and ex < 0.05 * total
+    cc = d["counts"].clone()
+    _, dl = voting.ransac_voting_layer_v3(mc, vc, 1024, inlier_thresh=0.99, seed=1, literal=True, return_debug=True)
+    assert torch.equal(cc, dl["counts"])
+    mn, vn_, _ = batch(32, 300, 480, 640, 40)
+    _, d = voting.ransac_voting_layer_v3(mn, vn_, 1024, inlier_thresh=0.99, seed=1, return_debug=True, band_stats=True)
+    assert d["layout"].cull == 1 and float(d["cull_bits"].float().mean()) < 0.1   # (a lucky draw of candidates may cull a key-point)
+    # a mixed batch: even images clean, odd images noisy
+    mm, vm = mn.clone(), vn_.clone()
+    mm[0::2], vm[0::2] = mc[0::2], vc[0::2]
+    out, d = voting.ransac_voting_layer_v3(mm, vm, 1024, inlier_thresh=0.99, seed=1, return_debug=True, band_stats=True)
+    bits = d["cull_bits"].clone()
+    assert bool(bits[0::2].all()) and float(bits[1::2].float().mean()) < 0.1
+    cm, wm = d["counts"].clone(), d["win"].clone()
+    out = out.clone()
+    lo, dl = voting.ransac_voting_layer_v3(mm, vm, 1024, inlier_thresh=0.99, seed=1, literal=True, return_debug=True)
+    assert torch.equal(cm, dl["counts"]) and torch.equal(wm, dl["win"])
+    assert float((out - lo).abs().max()) < 1e-3
+    cull(False)
+    of, df = voting.ransac_voting_layer_v3(mm, vm, 1024, inlier_thresh=0.99, seed=1, return_debug=True)
+    assert df["layout"].cull == 0 and torch.equal(df["counts"], cm) and torch.equal(of, out)

@@ -12,7 +12,7 @@ from oracle import refkernels
 from oracle import ransac_voting_oracle as O
 from pvnet_amd import synth, voting
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("cull_selection")]   # (tests/conftest.py: both selections of the disc culling)
 
 
 def dev():

@@ -10,7 +10,7 @@ from oracle import cref
 from oracle import ransac_voting_oracle as O
 from pvnet_amd import synth, voting
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("cull_selection")]   # (tests/conftest.py: both selections of the disc culling)
 
 TOL_PX = 1e-3  # north_star: key-points within 1e-3 px of the reference on identical inputs
 # votes per hypothesis by which FLOAT64 arithmetic (oracle64) may differ from the reference's float32 decisions on threshold-edge

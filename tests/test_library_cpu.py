@@ -28,7 +28,7 @@ def test_exports_every_declared_symbol(lib):
             "pvnet_voting_for_hypothesis_vanishing_point", "pvnet_vote_build_info"} <= names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/pvnet_vote.h but not exported"
-    assert lib.pvnet_vote_abi_version() == 8
+    assert lib.pvnet_vote_abi_version() == 9
     assert b"gfx950" in lib.pvnet_vote_build_info()
 
 
@@ -40,7 +40,7 @@ def test_host_pnp_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "pvnet_pnp.h")).read()
     body = hdr[hdr.index('extern "C"'):]
     names = set(re.findall(r"^(?:void|int)\s+([a-z0-9_]+)\s*\(", body, flags=re.M))
-    assert {"uncertainty_pnp", "pvnet_pnp_refine", "pvnet_pnp_evaluate", "pvnet_pnp_solve", "pvnet_pnp_solve_batch",
+    assert {"uncertainty_pnp", "pvnet_pnp_refine", "pvnet_pnp_evaluate", "pvnet_pnp_solve", "pvnet_pnp_solve_batch", "pvnet_pnp_poses_from_rt",
             "pvnet_angle_axis_to_matrix", "pvnet_matrix_to_angle_axis", "farthest_point_sampling",
             "farthest_point_sampling_init_center"} == names
     for n in names:

@@ -218,3 +218,25 @@ def test_native_library_is_clean_under_asan_ubsan(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "sanitized run done" in run.stdout
+
+
+def test_batch_solve_on_threads_equals_the_serial_loop(demo_fixture, monkeypatch):
+    """pvnet_pnp_solve_batch shares the poses of a batch out over threads (round 6; the serial loop of
+    tools/train_linemod.py:210-218): every pose must be bit-identical to the single-thread result, with and without weights,
+    including a degenerate image in the middle of a block"""
+    rng = np.random.default_rng(5)
+    X, K = demo_fixture["points_3d"], demo_fixture["K"]
+    n = 37
+    p2 = demo_fixture["points_2d"][None] + rng.normal(0, 0.7, size=(n, X.shape[0], 2))
+    p2[11] = 0.0   # degenerate: comes back as zeros
+    W = np.abs(rng.normal(1.0, 0.3, size=(n, X.shape[0], 3)))
+    W[:, :, 1] *= 0.1
+    for weights in (None, W):
+        monkeypatch.setenv("PVNET_PNP_THREADS", "1")
+        serial = P.pnp_batch(X, p2, K, weights)
+        for nt in ("2", "5", "8"):
+            monkeypatch.setenv("PVNET_PNP_THREADS", nt)
+            assert P.pnp_batch(X, p2, K, weights).tobytes() == serial.tobytes()
+        monkeypatch.delenv("PVNET_PNP_THREADS")
+        assert P.pnp_batch(X, p2, K, weights).tobytes() == serial.tobytes()
+    assert not serial[11].any() and serial[10].any()
