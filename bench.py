@@ -109,6 +109,10 @@ def parse(argv=None):
     ap.add_argument("--gather-bucket", type=int, default=0,
                     help="steps whose key-points travel in ONE all-gather (N > 1 or under torch.distributed.run); 0 = the "
                          "number of streams")
+    ap.add_argument("--gather", choices=("rccl", "torch"), default=os.environ.get("BENCH_GATHER", "rccl"),
+                    help="the all-gather of key-points under torch.distributed.run: 'rccl' = the library's own ncclAllGather on the "
+                         "voting stream that filled the bucket (pvnet_vote_allgather; torch.distributed only bootstraps the "
+                         "communicator), 'torch' = torch.distributed.all_gather_into_tensor on a communication stream (rounds 1-5)")
     ap.add_argument("--score-repeats", type=int, default=200, help="back-to-back scoring launches timed for the roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -551,7 +555,20 @@ def main(argv=None):
     G = max(1, a.gather_bucket if a.gather_bucket > 0 else nstreams)
     NBLK = 4  # staging / target blocks in rotation
     GATHER_ON_VOTE = os.environ.get("BENCH_GATHER_ON_VOTING_STREAM") == "1"
-    if dist is not None:
+    # Round 6 (--gather rccl, the default): the collective is the LIBRARY's ncclAllGather (pvnet_vote_allgather) and every voting stream
+    # gathers its OWN votes -- a bucket is GS consecutive steps of ONE stream, sent from that stream: stream order is the only
+    # dependency (no event, no communication stream, no wait across streams), and no ProcessGroup stream takes a hardware queue.
+    rg = None
+    if dist is not None and a.gather == "rccl":
+        from pvnet_amd import distributed as D
+        rg = D.RcclGather(dev)
+    GS = max(1, a.gather_bucket) if a.gather_bucket > 0 else 3   # steps per collective of a stream (rccl mode)
+    if rg is not None:
+        staging_s = [[torch.empty((GS, BATCH, VN, 2), dtype=torch.float32, device=dev) for _ in range(NBLK)] for _ in range(nstreams)]
+        gathered_s = [[torch.empty((world, GS, BATCH, VN, 2), dtype=torch.float32, device=dev) for _ in range(NBLK)] for _ in range(nstreams)]
+        sfill = [[0, 0] for _ in range(nstreams)]   # per stream: bucket index, slots filled
+        staging, gathered = staging_s[0], gathered_s[0]   # (the exchange timed alone below uses one block)
+    if dist is not None and rg is None:
         comm = None if GATHER_ON_VOTE else torch.cuda.Stream(dev)
         staging = [torch.empty((G, BATCH, VN, 2), dtype=torch.float32, device=dev) for _ in range(NBLK)]
         gathered = [torch.empty((world, G, BATCH, VN, 2), dtype=torch.float32, device=dev) for _ in range(NBLK)]
@@ -559,8 +576,21 @@ def main(argv=None):
     bucket = {"n": 0, "fill": 0, "used": set()}  # index of the bucket being filled, slots filled, streams that voted into it
     pending = []
 
+    def flush_stream(si):
+        """rccl mode: stream si sends its current bucket (a last, partly filled one whole: same size as every other) from ITSELF"""
+        n, k = sfill[si]
+        if k == 0:
+            return
+        with torch.cuda.stream(streams[si]):
+            rg.all_gather(gathered_s[si][n % NBLK], staging_s[si][n % NBLK])
+        sfill[si] = [n + 1, 0]
+
     def flush():
         """send the filled slots of the current bucket (all G of them, except for a last partial bucket)"""
+        if rg is not None:
+            for si in range(nstreams):
+                flush_stream(si)
+            return
         blk, k = bucket["n"] % NBLK, bucket["fill"]
         if k == 0:
             return
@@ -599,6 +629,15 @@ def main(argv=None):
                 return voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=SEED0 + i,
                                                      image_offset=rank * BATCH, workspace=spaces[i % ns], concurrent=conc,
                                                      **mode)
+            if rg is not None:   # a slot of this stream's own staging block; the gather that last read the block is earlier on this stream
+                si = i % ns
+                n, j = sfill[si]
+                out = voting.ransac_voting_layer_v3(m, v, HN, inlier_thresh=THRESH, seed=SEED0 + i, image_offset=rank * BATCH,
+                                                    out=staging_s[si][n % NBLK][j], workspace=spaces[si], concurrent=conc, **mode)
+                sfill[si][1] = j + 1
+                if j + 1 == GS:
+                    flush_stream(si)
+                return out
             blk, j = bucket["n"] % NBLK, bucket["fill"]
             # the gather that last read this block (NBLK buckets ago) must be complete before a vote overwrites a slot: with
             # four blocks in rotation it long is -- a host-side query, and a device-side wait only if it is not

@@ -221,6 +221,24 @@ int pvnet_vote_v3_stage_repeat(const void* mask, int mask_dtype, const int64_t m
 int pvnet_vote_band_margin(float thresh, uint32_t* out_stats, int b, int h, int w, int vn, int hn, int max_num,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * The path's one exchange, issued by the library (ABI 9; pvnet_amd/csrc/pvnet_rccl.hip).  Replaces the gather of
+ * torch.nn.DataParallel(EvalWrapper) (tools/train_linemod.py:183-184, tools/demo.py:174): every rank votes its own images and ONE
+ * ncclAllGather of count_per_rank float32 per rank -- on the stream the votes were issued on, so stream order is the only
+ * dependency -- gives every rank all key-points.  librccl is dlopen()ed on first use (`path` NULL: librccl.so, librccl.so.1,
+ * /opt/rocm/lib); nothing here links against it.  Return values: 0, PVNET_E_*, or RCCL's own ncclResult_t (> 0).
+ *   pvnet_rccl_load         host-only; explicit library path (e.g. the librccl.so PyTorch-ROCm ships), idempotent
+ *   pvnet_rccl_unique_id    128 bytes a single rank generates and the caller's bootstrap (torch.distributed, MPI, a file) hands to all
+ *   pvnet_rccl_comm_init    collective over the ranks, on the CURRENT device; *comm is the ncclComm_t
+ *   pvnet_vote_allgather    all [nranks * count_per_rank] <- every rank's local [count_per_rank]; no sync, no allocation
+ */
+int pvnet_rccl_load(const char* path);
+int pvnet_rccl_unique_id(void* id128);
+int pvnet_rccl_comm_init(void** comm, int nranks, const void* id128, int rank);
+int pvnet_rccl_comm_ranks(void* comm, int* nranks);
+int pvnet_rccl_comm_destroy(void* comm);
+int pvnet_vote_allgather(const float* local, float* all, size_t count_per_rank, void* comm, void* stream);
+
 /* Epilogues of the reference's sibling functions.  Both run on the WORKSPACE of a preceding pvnet_vote_v3 call with
  * the same (b,h,w,vn,hn,max_num) on the same stream (they read its compacted pixel lists, hypotheses and counts).
  *

@@ -13,7 +13,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", "pvnet_vote.hip"), os.path.join(HERE, "csrc", "pvnet_nn.hip")]
+SRC = [os.path.join(HERE, "csrc", "pvnet_vote.hip"), os.path.join(HERE, "csrc", "pvnet_nn.hip"),
+       os.path.join(HERE, "csrc", "pvnet_rccl.hip")]   # (the last one is host code only: the RCCL binding)
 DEPS = SRC + [os.path.join(HERE, "csrc", "pvnet_rng.h"), os.path.join(ROOT, "include", "pvnet_vote.h"),
               os.path.join(ROOT, "include", "pvnet_nn.h")]
 LIB = os.path.join(HERE, "libpvnet_vote.so")

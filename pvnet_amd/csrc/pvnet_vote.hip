@@ -982,6 +982,22 @@ __device__ __forceinline__ void kp_preamble(const VoteParams& P, int bi, int tn,
 // Padding hypotheses (>= hn) sort to the end; a tile without a real hypothesis is never scored.
 // Round 6: 256 threads with four keys each (round 5: 1 024 threads, one key each, 40 us for 288 blocks -- two rounds on 256 CUs and
 // sixteen waves per barrier); a block of four waves is resident wherever a hypothesis block is.
+// v of lane (l ^ M), M a power of two below 64, without the LDS crossbar's address operand: DPP for 1, 2 and 8 (quad_perm, row_ror:8),
+// gfx950's row / half-wave swaps for 16 and 32, ds_swizzle's bit mode for 4
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v, int m) {
+    if (m == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1, 0, 3, 2]
+    if (m == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2, 3, 0, 1]
+    if (m == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);               // and 0x1F, or 0, xor 4
+    if (m == 8) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);   // row_ror:8
+    const int lane = (int)(threadIdx.x & 63);
+    if (m == 16) {   // rows of 16 lanes: r[0] = (R0, R0, R2, R2), r[1] = (R1, R1, R3, R3)
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane & 16) ? r[0] : r[1];
+    }
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // r[0] = (lo, lo), r[1] = (hi, hi)
+    return (lane & 32) ? r[0] : r[1];
+}
+
 // (-DPVNET_K3_PROBE, tools/experiments/k3_probe.py: shader-clock stamps of the block's phases into the unused tail of the item list)
 #ifdef PVNET_K3_PROBE
 #define PV_K3_STAMP(i) do { if (threadIdx.x == 0) k3_stamp[i] = (int)(clock64() - k3_t0); } while (0)
@@ -1036,7 +1052,8 @@ __device__ __forceinline__ void cull_block(const VoteParams& P, int bi, int k, i
     }
     PV_K3_STAMP(1);   // hypotheses
     // ---- sort keys: position on a Hilbert curve of 1/8-pixel cells about the origin (11 bits per coordinate: +-128 px); far and
-    //      non-finite hypotheses clamp to the border.  (a thread reads back only what it wrote: no barrier yet)
+    //      non-finite hypotheses clamp to the border.  (a thread reads back only what it wrote: no barrier yet; which slot of the
+    //      sort a key starts in does not matter)
     constexpr int idxbits = 10, cbits = (32 - idxbits) >> 1;
     uint32_t key[E];
     {
@@ -1055,95 +1072,120 @@ __device__ __forceinline__ void cull_block(const VoteParams& P, int bi, int k, i
         }
     }
     PV_K3_STAMP(2);   // keys
-    // ---- bitonic sort, ascending, slot i = e * 256 + tid: partners 1 .. 32 lanes away by shuffle, 64 / 128 threads away through
-    //      LDS (two barriers), 256 / 512 slots away in the thread's own registers
+    // ---- bitonic sort, ascending, of the 1 024 keys at slot i = 4 tid + e (round 6b; the first form, slot = 256 e + tid with
+    //      __shfl_xor, took 23 700 cycles: 45 of the 55 stages crossed lanes through the LDS crossbar).  Now 19 stages (partners 1 and 2
+    //      slots away) stay in the thread's own registers, 33 cross LANES -- by DPP (lane ^ 1, ^ 2, ^ 8), v_permlane16_swap /
+    //      v_permlane32_swap (^ 16, ^ 32) and one ds_swizzle (^ 4) -- and 3 cross WAVES through LDS.
     auto cas = [&](uint32_t& mine_, uint32_t other, int i, int kk, int jj) {
         const bool keep_min = ((i & jj) == 0) == ((i & kk) == 0);
         const uint32_t lo = mine_ < other ? mine_ : other, hi = mine_ < other ? other : mine_;
         mine_ = keep_min ? lo : hi;
     };
-    for (int kk = 2; kk <= CULL_HN; kk <<= 1)
+#pragma unroll
+    for (int kk = 2; kk <= CULL_HN; kk <<= 1) {
+#pragma unroll
         for (int jj = kk >> 1; jj > 0; jj >>= 1) {
-            if (jj >= NT) {   // (block-uniform)
-                if (jj == NT) {
-                    { const uint32_t a = key[0], c = key[1]; cas(key[0], c, tid, kk, jj); cas(key[1], a, NT + tid, kk, jj); }
-                    { const uint32_t a = key[2], c = key[3]; cas(key[2], c, 2 * NT + tid, kk, jj); cas(key[3], a, 3 * NT + tid, kk, jj); }
-                } else {
-                    { const uint32_t a = key[0], c = key[2]; cas(key[0], c, tid, kk, jj); cas(key[2], a, 2 * NT + tid, kk, jj); }
-                    { const uint32_t a = key[1], c = key[3]; cas(key[1], c, NT + tid, kk, jj); cas(key[3], a, 3 * NT + tid, kk, jj); }
-                }
-            } else if (jj >= 64) {
+            if (jj == 1) {
+                { const uint32_t a = key[0], c = key[1]; cas(key[0], c, 4 * tid, kk, 1); cas(key[1], a, 4 * tid + 1, kk, 1); }
+                { const uint32_t a = key[2], c = key[3]; cas(key[2], c, 4 * tid + 2, kk, 1); cas(key[3], a, 4 * tid + 3, kk, 1); }
+            } else if (jj == 2) {
+                { const uint32_t a = key[0], c = key[2]; cas(key[0], c, 4 * tid, kk, 2); cas(key[2], a, 4 * tid + 2, kk, 2); }
+                { const uint32_t a = key[1], c = key[3]; cas(key[1], c, 4 * tid + 1, kk, 2); cas(key[3], a, 4 * tid + 3, kk, 2); }
+            } else if (jj >= 256) {   // the partner is one / two waves away
 #pragma unroll
-                for (int e = 0; e < E; ++e) s_key[e * NT + tid] = key[e];
+                for (int e = 0; e < E; ++e) s_key[4 * tid + e] = key[e];
                 __syncthreads();
 #pragma unroll
-                for (int e = 0; e < E; ++e) cas(key[e], s_key[(e * NT + tid) ^ jj], e * NT + tid, kk, jj);
+                for (int e = 0; e < E; ++e) cas(key[e], s_key[(4 * tid + e) ^ jj], 4 * tid + e, kk, jj);
                 __syncthreads();
-            } else {
+            } else {                  // the partner is lane ^ (jj / 4)
 #pragma unroll
-                for (int e = 0; e < E; ++e) cas(key[e], (uint32_t)__shfl_xor((int)key[e], jj, 64), e * NT + tid, kk, jj);
+                for (int e = 0; e < E; ++e) cas(key[e], lane_xor(key[e], jj >> 2), 4 * tid + e, kk, jj);
             }
         }
+    }
     __syncthreads();   // (s_h of the other threads: every hypothesis has been written -- the sort's own barriers already saw to it)
     PV_K3_STAMP(3);   // sort
-    // ---- sorted outputs + one disc per tile of 32 sorted hypotheses: a tile = the 32 lanes of a half-wave (slot p = e * 256 + tid)
+    // ---- sorted outputs + one disc per tile of 32 sorted hypotheses: a tile = the 4 slots of 8 consecutive threads (slot p = 4 tid + e)
     constexpr uint32_t imask = (uint32_t)CULL_HN - 1u;
     constexpr int ntl = CULL_HN >> 5;
+    float hxo[E], hyo[E];
+    bool real[E];
+    int4 pj;
+    float mnx = 3.0e38f, mxx = -3.0e38f, mny = 3.0e38f, mxy = -3.0e38f;
+    int bad = 0, nreal = 0;
+    {
+        float2 hv[E];
+        int jv[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            jv[e] = (int)(key[e] & imask);
+            real[e] = jv[e] < P.hn;
+            hv[e] = real[e] ? s_h[jv[e]] : make_float2(0.f, 0.f);
+            hxo[e] = hv[e].x - ox;
+            hyo[e] = hv[e].y - oy;
+            // the tile's bounding box, whether it holds a far / non-finite hypothesis (the tile is then scored in full), how many real ones
+            mnx = real[e] ? fminf(mnx, hxo[e]) : mnx;
+            mxx = real[e] ? fmaxf(mxx, hxo[e]) : mxx;
+            mny = real[e] ? fminf(mny, hyo[e]) : mny;
+            mxy = real[e] ? fmaxf(mxy, hyo[e]) : mxy;
+            bad |= (real[e] && (!(fabsf(hxo[e]) < BAND_FAR) || !(fabsf(hyo[e]) < BAND_FAR))) ? 1 : 0;
+            nreal += real[e] ? 1 : 0;
+        }
+        pj = make_int4(jv[0], jv[1], jv[2], jv[3]);
+        *reinterpret_cast<int4*>(P.perm + bk * CULL_HN + 4 * tid) = pj;
+        *reinterpret_cast<int4*>(P.cnts + bk * CULL_HN + 4 * tid) = make_int4(0, 0, 0, 0);   // K4 accumulates into them
+        float4* const oh = reinterpret_cast<float4*>(P.hyps + bk * CULL_HN + 4 * tid);
+        oh[0] = make_float4(hv[0].x, hv[0].y, hv[1].x, hv[1].y);
+        oh[1] = make_float4(hv[2].x, hv[2].y, hv[3].x, hv[3].y);
+    }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const int p = e * NT + tid;
-        const int j = (int)(key[e] & imask);
-        const bool real = j < P.hn;
-        const float2 hv = real ? s_h[j] : make_float2(0.f, 0.f);
-        P.perm[bk * CULL_HN + p] = j;
-        P.hyps[bk * CULL_HN + p] = hv;
-        P.cnts[bk * CULL_HN + p] = 0;   // K4 accumulates into it
-        const float hxo = hv.x - ox, hyo = hv.y - oy;
         uint4 lo = make_uint4(0u, 0u, 0u, 0u), hi = make_uint4(0u, 0u, 0u, pk(0u, 0x3F80u));
-        if (real) b_col_exact(hxo, hyo, rho, P.kband, lo, hi);
-        uint4* o = P.hypb + (bk * CULL_HN + p) * 2;
+        if (real[e]) b_col_exact(hxo[e], hyo[e], rho, P.kband, lo, hi);
+        uint4* o = P.hypb + (bk * CULL_HN + 4 * tid + e) * 2;
         o[0] = lo;
         o[1] = hi;
-        // the tile's bounding box, whether it holds a far / non-finite hypothesis, how many real ones: over the 32 lanes
-        float mnx = real ? hxo : 3.0e38f, mxx = real ? hxo : -3.0e38f, mny = real ? hyo : 3.0e38f, mxy = real ? hyo : -3.0e38f;
-        int bad = (real && (!(fabsf(hxo) < BAND_FAR) || !(fabsf(hyo) < BAND_FAR))) ? 1 : 0;   // far, Inf or NaN: the tile is scored in full
-        int nreal = real ? 1 : 0;
+    }
 #pragma unroll
-        for (int off = 16; off > 0; off >>= 1) {
-            mnx = fminf(mnx, __shfl_xor(mnx, off, 64));
-            mxx = fmaxf(mxx, __shfl_xor(mxx, off, 64));
-            mny = fminf(mny, __shfl_xor(mny, off, 64));
-            mxy = fmaxf(mxy, __shfl_xor(mxy, off, 64));
-            bad |= __shfl_xor(bad, off, 64);
-            nreal += __shfl_xor(nreal, off, 64);
-        }
-        const float qx = 0.5f * (mnx + mxx), qy = 0.5f * (mny + mxy);   // centre, relative to the origin
-        const float dx = hxo - qx, dy = hyo - qy;
-        float r2 = (real && !bad) ? fmaf(dx, dx, dy * dy) : 0.f;
+    for (int off = 1; off < 8; off <<= 1) {   // over the tile's 8 threads
+        mnx = fminf(mnx, __uint_as_float(lane_xor(__float_as_uint(mnx), off)));
+        mxx = fmaxf(mxx, __uint_as_float(lane_xor(__float_as_uint(mxx), off)));
+        mny = fminf(mny, __uint_as_float(lane_xor(__float_as_uint(mny), off)));
+        mxy = fmaxf(mxy, __uint_as_float(lane_xor(__float_as_uint(mxy), off)));
+        bad |= (int)lane_xor((uint32_t)bad, off);
+        nreal += (int)lane_xor((uint32_t)nreal, off);
+    }
+    const float qx = 0.5f * (mnx + mxx), qy = 0.5f * (mny + mxy);   // centre, relative to the origin
+    float r2 = 0.f;
 #pragma unroll
-        for (int off = 16; off > 0; off >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, off, 64));
-        if ((tid & 31) == 0) {
-            uint4 clo = make_uint4(0u, 0u, 0u, 0u), chi = make_uint4(0u, 0u, 0u, pk(0u, 0x3F80u));
-            float g = 0.f;
-            if (nreal > 0 && !bad) {
-                const float Rq = __builtin_sqrtf(fmaf(qx, qx, qy * qy)) * 1.000001f;
-                // radius of the disc about the point the column REALLY encodes (fl(q s) / s): the roundings of h - o, q, h - q, the
-                // square root and q s are relative 2^-24 each, of |h - o| <= Rq + rt at most
-                const float rt = __builtin_sqrtf(r2) * 1.000001f;
-                const float rtu = rt + 4.0e-7f * (Rq + rt);
-                const float G = rtu / P.thresh * 1.000001f;
-                const float Eb = P.kband * (Rq + rtu + rho);
-                const float Sg = G + Eb;
-                const float sc = bf16_floor(BAND_TARGET / Sg);
-                b_col_scaled(qx, qy, Rq + rtu, sc, clo, chi);
-                if (sc > 0.f && Rq + rtu < BAND_FAR) g = G / Sg * 0.99999f;   // (rounded down: the certainty threshold 1 - g (1 - mu) only grows)
-            }
-            const int T = p >> 5;
-            uint4* oc = P.hypc + (bk * ntl + T) * 2;
-            oc[0] = clo;
-            oc[1] = chi;
-            P.hypg[bk * ntl + T] = g;
+    for (int e = 0; e < E; ++e) {
+        const float dx = hxo[e] - qx, dy = hyo[e] - qy;
+        r2 = (real[e] && !bad) ? fmaxf(r2, fmaf(dx, dx, dy * dy)) : r2;
+    }
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) r2 = fmaxf(r2, __uint_as_float(lane_xor(__float_as_uint(r2), off)));
+    if ((tid & 7) == 0) {
+        uint4 clo = make_uint4(0u, 0u, 0u, 0u), chi = make_uint4(0u, 0u, 0u, pk(0u, 0x3F80u));
+        float g = 0.f;
+        if (nreal > 0 && !bad) {
+            const float Rq = __builtin_sqrtf(fmaf(qx, qx, qy * qy)) * 1.000001f;
+            // radius of the disc about the point the column REALLY encodes (fl(q s) / s): the roundings of h - o, q, h - q, the
+            // square root and q s are relative 2^-24 each, of |h - o| <= Rq + rt at most
+            const float rt = __builtin_sqrtf(r2) * 1.000001f;
+            const float rtu = rt + 4.0e-7f * (Rq + rt);
+            const float G = rtu / P.thresh * 1.000001f;
+            const float Eb = P.kband * (Rq + rtu + rho);
+            const float Sg = G + Eb;
+            const float sc = bf16_floor(BAND_TARGET / Sg);
+            b_col_scaled(qx, qy, Rq + rtu, sc, clo, chi);
+            if (sc > 0.f && Rq + rtu < BAND_FAR) g = G / Sg * 0.99999f;   // (rounded down: the certainty threshold 1 - g (1 - mu) only grows)
         }
+        const int T = tid >> 3;
+        uint4* oc = P.hypc + (bk * ntl + T) * 2;
+        oc[0] = clo;
+        oc[1] = chi;
+        P.hypg[bk * ntl + T] = g;
     }
     PV_K3_STAMP(4);   // outputs issued
 }
@@ -2178,6 +2220,7 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
             }
         }
         lds_barrier();
+        PV_PHASE(1);   // (TIMED, this kernel: 0 staging, 1 coarse pass + barrier, 2 fine pass, 3 flush + cell list + re-evaluation + barriers)
         // ---- fine pass: the uncertain pixels of each of this wave's eight hypothesis tiles, gathered into groups of 32
 #pragma unroll
         for (int t = 0; t < MH; ++t) {   // pad the wave's own lists to whole groups with the dead row (wave-local: LDS operations of a wave stay in order)
@@ -2244,7 +2287,7 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
 #undef PV_XS
 #undef PV_LO
 #undef PV_HI
-        PV_PHASE(1);
+        PV_PHASE(2);
         int colx = col;
         asm volatile("" : "+v"(colx));
         const bool padded = h0 + MH * 32 > P.hn;
@@ -2263,7 +2306,6 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
             }
         }
         lds_barrier();
-        PV_PHASE(2);
         // ---- flagged cells, decided by the reference's arithmetic: 16 lanes per cell, one gathered pixel each
         const int ncell = s_ncell;
         if (ncell > 0) {

@@ -175,7 +175,12 @@ def _debug_views(ws: torch.Tensor, L: Layout):
         return ws[off:off + nbytes].view(dtype).view(*shape)
     b, vn, cap, hp = L.b, L.vn, L.cap, L.hn_pad
     ctrl = view(L.off_ctrl, 4 * 8 * (b + 1), torch.int32, (b + 1, 8))
+    cull = {}
+    if L.cull:  # disc culling: sorted position -> caller's hypothesis index, the hypotheses in sorted order (culled key-points only)
+        cull = dict(perm=view(L.off_perm, 4 * b * vn * hp, torch.int32, (b, vn, hp)),
+                    hyps=view(L.off_hyps, 8 * b * vn * hp, torch.float32, (b, vn, hp, 2)))
     return dict(
+        **cull,
         layout=L, ctrl=ctrl, tn0=ctrl[:b, 0], tn=ctrl[:b, 1], nchunks=ctrl[:b, 4], total_items=ctrl[b, 0],
         bits=view(L.off_bits, 8 * b * L.words, torch.int64, (b, L.words)),
         pix=view(L.off_pix, 4 * b * cap, torch.int32, (b, cap)),

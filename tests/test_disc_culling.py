@@ -205,3 +205,43 @@ def test_the_library_selects_clean_key_points_and_leaves_noisy_ones_to_the_full_
     cull(False)
     of, df = voting.ransac_voting_layer_v3(mm, vm, 1024, inlier_thresh=0.99, seed=1, return_debug=True)
     assert df["layout"].cull == 0 and torch.equal(df["counts"], cm) and torch.equal(of, out)
+
+
+def hilbert_index(x, y, bits):
+    """numpy restatement of hilbert_index() (pvnet_vote.hip): position of integer cells (x, y) on the 2^bits x 2^bits Hilbert curve"""
+    x, y = x.astype(np.uint32).copy(), y.astype(np.uint32).copy()
+    d = np.zeros_like(x)
+    s = np.uint32(1 << (bits - 1))
+    while s > 0:
+        rx, ry = ((x & s) != 0).astype(np.uint32), ((y & s) != 0).astype(np.uint32)
+        d += s * s * ((np.uint32(3) * rx) ^ ry)
+        flip = (ry == 0) & (rx == 1)
+        x, y = np.where(flip, ~x, x), np.where(flip, ~y, y)
+        swap = ry == 0
+        x, y = np.where(swap, y, x), np.where(swap, x, y)
+        s = np.uint32(s >> 1)
+    return d
+
+
+def test_the_sorted_order_is_a_permutation_along_the_hilbert_curve(cull):
+    """the K3 block of a culled key-point: `perm` must be a permutation of the hypothesis indices (padding behind), `hyps` the
+    hypotheses in that order, and the order the one of the sort keys -- (Hilbert position of the hypothesis' 1/8-pixel cell about
+    the band origin, caller index): the 256-thread register / DPP / permlane sorting network against numpy's sort of the same keys"""
+    m, v, _ = batch(3, 120, 480, 640, 40)
+    cull(True)
+    hn = 1000
+    _, d = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=0.99, seed=13, return_debug=True)
+    assert bool(d["cull_bits"].all())
+    perm, hyps, hyp = d["perm"].cpu().numpy(), d["hyps"].cpu().numpy(), d["hyp"].cpu().numpy()
+    org = d["band_origin"].cpu().numpy().astype(np.float32)
+    for bi in range(3):
+        for k in range(9):
+            p = perm[bi, k]
+            assert sorted(p.tolist()) == list(range(1024))
+            assert (p[:hn] < hn).all() and (p[hn:] >= hn).all()          # padding sorts behind every real hypothesis
+            assert hyps[bi, k, :hn].tobytes() == hyp[bi, k][p[:hn]].tobytes()
+            cells = np.float32(2048.0)
+            fx = np.clip((hyp[bi, k, :, 0] - org[bi, k, 0]) * np.float32(8.0) + np.float32(0.5) * cells, 0, cells - 1)
+            fy = np.clip((hyp[bi, k, :, 1] - org[bi, k, 1]) * np.float32(8.0) + np.float32(0.5) * cells, 0, cells - 1)
+            key = (hilbert_index(fx.astype(np.uint32), fy.astype(np.uint32), 11).astype(np.uint64) << np.uint64(10)) | np.arange(hn, dtype=np.uint64)
+            assert (p[:hn] == np.argsort(key, kind="stable")).all()
