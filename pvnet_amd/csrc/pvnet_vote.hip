@@ -99,6 +99,9 @@ constexpr int K1_WAVES = PVNET_K1_WAVES;  // waves per K1 workgroup (one workgro
                                           // 160 VGPRs per SIMD at once, one of 8 fits beside the resident scoring waves of another
                                           // batch (PVNET_F_CONCURRENT): +3 % with six batches in flight for -0.5 % alone
 constexpr int K1_WORDS_PER_WAVE = SEG_WORDS / K1_WAVES;  // independent loads in flight per lane
+static_assert(SEG_WORDS == 64, "a segment's bit words are stored by the 64 lanes of one wave (mask_bits kernels, compact_kernel's scan)");
+static_assert(K1_WAVES <= SEG_WORDS / 2 && (SEG_WORDS / 2) % K1_WAVES == 0,
+              "PVNET_K1_WAVES must divide 32: mask_bits_pair_kernel gives every wave (SEG_WORDS / 2) / K1_WAVES double words");
 constexpr int K2_WORDS_PER_BLOCK = SEG_WORDS;
 // thinning: keep a pixel <=> pvnet_thin_bin(random word) < K (pvnet_rng.h; oracle: subsample_threshold): 1/1024 steps of the
 // probability down to 1/64, sixteen steps per octave below (round 4; rounds 2-3: the top ten bits only)
@@ -818,8 +821,8 @@ constexpr int ITEM_CULL_SHIFT = 16;
 __device__ __forceinline__ int item_kp(int y) { return y & 0xFFFF; }
 __device__ __forceinline__ bool item_culled(int y) { return (y >> ITEM_CULL_SHIFT) != 0; }
 
-// kp_cull: [vn] 0 / 1 in LDS -- which key-points of this image the disc-culling kernel scores (nullptr: none)
-__device__ __forceinline__ void plan_image(const VoteParams& P, int bi, const int* kp_cull) {
+// culled: the disc-culling kernel scores this image's key-points (their items carry the mark)
+__device__ __forceinline__ void plan_image(const VoteParams& P, int bi, bool culled) {
     constexpr int NT = 256;
     __shared__ int s_part[NT / 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -854,7 +857,7 @@ __device__ __forceinline__ void plan_image(const VoteParams& P, int bi, const in
     for (int local = threadIdx.x; local < n; local += NT) {
         const int hq = local % HQ, t = local / HQ;
         const int k = t / nchg;
-        const int flag = (kp_cull && kp_cull[k]) ? (1 << ITEM_CULL_SHIFT) : 0;
+        const int flag = culled ? (1 << ITEM_CULL_SHIFT) : 0;
         P.items[base + local] = make_int4(bi, k | flag, t % nchg, hq);  // (image, key-point | culled, chunk group, hyp slice)
     }
 }
@@ -891,16 +894,24 @@ constexpr int NCAND = 8, KP_MAX = 32;      // candidate intersections per key-po
 //            component-wise median, rounded to integers.  It only scales the band -- no result depends on it -- so a bad estimate
 //            (fewer than three usable candidates: the image's median pixel instead) costs re-evaluations, never correctness.
 //   culling  P.cull = 1: every key-point (PVNET_SCORE_CULL=1: tests and probes); P.cull = 2 (the default where the layout supports
-//            it): the key-points whose candidates lie close together -- spread S (median Chebyshev distance from the median point)
-//            <= cull_q rho tan(theta0), i.e. the field's angular noise is small against the threshold angle, so most pixels are
-//            certain for most hypothesis tiles and the gathered rest is cheaper than the dense sweep (crossover measured:
-//            profiles/r06_cull_crossover.txt).  Any choice gives the same counts; a wrong one only costs time.
+//            it): a key-point VOTES for culling when its candidates lie close together -- spread S (median Chebyshev distance
+//            from the median point) <= cull_q rho tan(theta0), i.e. the field's angular noise is small against the threshold
+//            angle, so most pixels are certain for most hypothesis tiles and the gathered rest is cheaper than the dense sweep
+//            (crossover measured: profiles/r06_cull_crossover.txt) -- and the IMAGE's key-points are culled together when the
+//            majority votes so (image_culled()): the spread of eight candidates scatters, and a call whose key-points split between
+//            the two scoring kernels pays the fixed cost of both (r06d: 220 us against 197 none / 174 all culled at sigma 0.01).
+//            Any choice gives the same counts; a wrong one only costs time.
 struct KpShared {
     float cand[KP_MAX * NCAND * 2];
     float med[KP_MAX * 2];
     int org[KP_MAX * 2];
-    int cull[KP_MAX];
+    int vote[KP_MAX];      // 1: this key-point's candidates say "cull"
 };
+__device__ __forceinline__ bool image_culled(const KpShared& S, int vn) {   // (after kp_preamble's last barrier; every thread the same)
+    int votes = 0;
+    for (int kk = 0; kk < vn; ++kk) votes += S.vote[kk];
+    return 2 * votes > vn;
+}
 __device__ __forceinline__ void kp_preamble(const VoteParams& P, int bi, int tn, bool live, KpShared& S) {
     int pm = 0;
     if (live) pm = P.pix[(size_t)bi * P.cap + tn / 2];
@@ -957,12 +968,12 @@ __device__ __forceinline__ void kp_preamble(const VoteParams& P, int bi, int tn,
             const bool kp = (dj + rho) * (1.f + (dist + ro) / rho) < (dist + dj + rho) * (1.f + ro / rho);
             S.org[kk * 2] = kp ? (int)rintf(mx) : pm % P.w;
             S.org[kk * 2 + 1] = kp ? (int)rintf(my) : pm / P.w;
-            S.cull[kk] = P.cull == 1 || (P.cull == 2 && kp && dj <= P.cull_q * rho * P.tau) ? 1 : 0;
+            S.vote[kk] = P.cull == 1 || (P.cull == 2 && kp && dj <= P.cull_q * rho * P.tau) ? 1 : 0;
         }
     } else if (mine && j == 0) {   // fewer than three usable candidates
         S.org[kk * 2] = pm % P.w;
         S.org[kk * 2 + 1] = pm / P.w;
-        S.cull[kk] = (P.cull == 1 && live) ? 1 : 0;
+        S.vote[kk] = (P.cull == 1 && live) ? 1 : 0;
     }
     __syncthreads();
 }
@@ -1244,7 +1255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(20))) void hypo
             int32_t* o = band_origin_ptr(P, bk);
             o[0] = S.org[threadIdx.x * 2];
             o[1] = S.org[threadIdx.x * 2 + 1];
-            *kp_cull_ptr(P, bk) = P.cull ? S.cull[threadIdx.x] : 0;
+            *kp_cull_ptr(P, bk) = (P.cull && image_culled(S, P.vn)) ? 1 : 0;
         }
     } else if (!LITERAL && P.mode && P.exact && blk == 0) {   // more than KP_MAX key-points: the image's median pixel for all of them
         int pm = 0;
@@ -1256,16 +1267,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(20))) void hypo
             *kp_cull_ptr(P, (size_t)bi * P.vn + kk) = 0;
         }
     }
-    const bool culling = !LITERAL && P.cull && kp_origin;   // (fill_params: P.cull implies the exact mode and vn <= KP_MAX)
+    // (fill_params: P.cull implies the exact mode and vn <= KP_MAX) this image's key-points go to the disc-culling kernel
+    const bool culling = !LITERAL && P.cull && kp_origin && live && image_culled(S, P.vn);
     if (blk == nbd) {      // one extra block per image plans its scoring work items (consumed by the next launches only)
-        plan_image(P, bi, culling ? S.cull : nullptr);
+        plan_image(P, bi, culling);
         return;
     }
     if (blk > nbd) {       // the block of key-point blk - nbd - 1: sorted operands and tile discs, if that key-point is culled
         __shared__ float2 s_h[CULL_HN];
         __shared__ uint32_t s_key[CULL_HN];
         const int k = blk - nbd - 1;
-        if (culling && live && S.cull[k]) cull_block(P, bi, k, tn, S, s_h, s_key, k3_t0);   // (block-uniform)
+        if (culling) cull_block(P, bi, k, tn, S, s_h, s_key, k3_t0);   // (block-uniform)
         return;
     }
     if (i < P.hn * P.vn) {
@@ -1277,7 +1289,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(20))) void hypo
     }
     P.hyp[((size_t)bi * P.vn + k) * P.hn_pad + h] = make_float2(hx, hy);
     if (P.atomic_counts) P.counts[((size_t)bi * P.vn + k) * P.hn_pad + h] = 0;  // K4 accumulates into it
-    if (!LITERAL && P.mode && !(culling && S.cull[k])) {  // the same hypothesis about the band origin, as a bf16x3 B operand column
+    if (!LITERAL && P.mode && !culling) {  // the same hypothesis about the band origin, as a bf16x3 B operand column
         float ox = 0.f, oy = 0.f;                         // (a culled key-point's columns are written, in sorted order, by its own block)
         if (kp_origin) {
             ox = (float)S.org[k * 2];
@@ -1736,9 +1748,14 @@ constexpr float BAND_CLEAN = 1.0f;     // a cell whose minimum |a'|, |b'| reache
 //           votes in their counters: loaded / flushed once per run instead of once per 256-pixel item.  Same-box A/B
 //           (profiles/r04_ab_runs.txt): +2 % with six batches in flight (less work), -4.5 % for a batch alone (the contiguous
 //           mapping itself: a launch of strided items ends more evenly) -- so it is what calls flagged PVNET_F_CONCURRENT run.
-template <int MH, int FOLD, bool TIMED, int NACC, bool RUNS_>
-__device__ __forceinline__ void score_exact_body(VoteParams P) {
-    if (MH == 8 && NACC == 2) PVNET_SPARE_VGPRS(167);
+// HEAD (round 6): the body is the FIRST of the two a merged launch runs (score_exact_both_kernel: the dense items here, the
+//           disc-culled ones in score_cull_body behind it) -- the kernel's register allocation and its closing clock stamps are
+//           the second body's.  Returns whether the workgroup met a disc-culled item on its walk (workgroup-uniform): the second body
+//           is only entered then, so a call without culled key-points pays one compare per item for the merged launch.
+template <int MH, int FOLD, bool TIMED, int NACC, bool RUNS_, bool HEAD = false>
+__device__ __forceinline__ bool score_exact_body(VoteParams P) {
+    if (HEAD) { }
+    else if (MH == 8 && NACC == 2) PVNET_SPARE_VGPRS(167);
     else if (MH == 8 && RUNS_) PVNET_SPARE_VGPRS(135);
     else if (MH == 8) PVNET_SPARE_VGPRS(127);  // (one pair, strided items: what a batch ALONE runs, four waves per SIMD)
     else if (MH == 4) PVNET_SPARE_VGPRS(143);
@@ -1797,10 +1814,14 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
 #pragma unroll
         for (int t = 0; t < MH; ++t) cnt[t] = 0u;
     };
+    bool met_culled = false;
     const ItemRange ir = my_items<RUNS>(P, total);
     for (int item = ir.first; item < ir.end; item += ir.step) {
         const int4 desc = P.items[item];
-        if (item_culled(desc.y)) continue;   // (workgroup-uniform) a key-point the disc-culling kernel scores: that launch takes the item
+        if (item_culled(desc.y)) {   // (workgroup-uniform) a key-point the disc-culling body scores
+            met_culled = true;
+            continue;
+        }
         const int bi = desc.x, k = item_kp(desc.y), cg = desc.z, hq = desc.w;
         const int tn = ctrl[bi * CTRL_STRIDE + C_TN];
         const float rho = band_rho(tn);
@@ -2006,7 +2027,7 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
         }
     }
     if (RUNS && run_key >= 0) flush_counts(run_bk, run_h0);
-    if (TIMED) {
+    if (TIMED && !HEAD) {
         lds_barrier();
         PV_PHASE(3);
         if (threadIdx.x == 0) {
@@ -2016,6 +2037,7 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
         }
     }
 #undef PV_PHASE
+    return met_culled;
 }
 // The register allocator fills whatever budget the occupancy target leaves (3 waves per SIMD: up to 168 VGPRs), the library needs
 // the top granule of every allocation unused (PVNET_SPARE_VGPRS): amdgpu_num_vgpr -- a literal, hence one definition per
@@ -2056,19 +2078,26 @@ PV_DEF_SCORE_EXACT4(8, 1, 1, 128) PV_DEF_SCORE_EXACT4(8, 2, 1, 160)
 // uncertain ones run the very same arithmetic.  What changes is the work: on the noisy benchmark field 59 % of the steps remain
 // at thresh 0.99 (simulation: tools/cull_study.py, profiles/r05_cull_study.txt), none on a clean field.
 // ------------------------------------------------------------------------------------------------------------
-template <bool TIMED, bool RUNS>
+// TAIL (round 6): the second body of a merged launch (the dense items were scored by score_exact_body<..., HEAD> before it, which also
+//           took the opening clock stamp)
+template <bool TIMED, bool RUNS, bool TAIL = false>
 __device__ __forceinline__ void score_cull_body(VoteParams P) {
     constexpr int MH = 8;
-    PVNET_SPARE_VGPRS(143);   // (136 usable: three waves per SIMD -- which the 48 KB of LDS per workgroup allow anyway)
+    // the merged kernel's allocation is the dense kernel's of the same item mapping: 136 VGPRs for contiguous runs (batches in flight: what
+    // is left of the SIMD's 512 holds other streams' small stages -- at 144 the six-stream rate fell 2.8 %, r06g), 128 for a batch
+    // alone (four waves per SIMD, four workgroups of 40 KB per CU).  This body spills a few per-item constants to fit.
+    if (RUNS) PVNET_SPARE_VGPRS(135); else PVNET_SPARE_VGPRS(127);
     unsigned long long* __restrict__ stamps = reinterpret_cast<unsigned long long*>(P.pix);
-    if (TIMED && threadIdx.x == 0) stamps[2 * blockIdx.x] = (unsigned long long)wall_clock64();
+    if (TIMED && !TAIL && threadIdx.x == 0) stamps[2 * blockIdx.x] = (unsigned long long)wall_clock64();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint4* s_t = reinterpret_cast<uint4*>(smem);                                  // 8 A tiles + the dead row's tile: 9 x 2 KB
-    float4* s_raw = reinterpret_cast<float4*>(s_t + 9 * TILE_U4);                 // raw records of the pixel group
-    unsigned* s_cells = reinterpret_cast<unsigned*>(s_raw + CULL_NPX);            // flagged cells of this item (4 * MH * 64 slots)
-    uint16_t* s_list = reinterpret_cast<uint16_t*>(s_cells + 4 * MH * 64);        // [32 tiles][256] A-row addresses of the uncertain pixels
+    unsigned* s_cells = reinterpret_cast<unsigned*>(s_t + 9 * TILE_U4);           // flagged cells of this item (4 * MH * 64 slots)
+    // (no copy of the raw records here: the few flagged cells read theirs back from HBM / L2 -- with it the workgroup was 4 KB above the
+    //  dense kernel's LDS, and the merged launch must not hold fewer workgroups per CU than the dense one)
+    uint8_t* s_list = reinterpret_cast<uint8_t*>(s_cells + 4 * MH * 64);          // [32 tiles][256] the uncertain pixels (index in the item: one byte
+                                                                                  // -- with 16-bit row addresses the workgroup took 48 KB, three per CU)
     float* s_sig = reinterpret_cast<float*>(s_list + 32 * CULL_NPX);              // [256] 1 - mu_i
     int* s_nu = reinterpret_cast<int*>(s_sig + CULL_NPX);                         // [32] uncertain pixels per hypothesis tile
     int* s_cv = s_nu + 32;                                                        // [32] certain votes per hypothesis tile
@@ -2113,6 +2142,13 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
 #pragma unroll
         for (int t = 0; t < MH; ++t) cnt[t] = 0u;
     };
+    // Round 6: the record of this thread's pixel of the NEXT item is requested while the current item is scored.  On the fields where
+    // culling pays, an item is a chain of waits (descriptor -> pixel count -> record -> barrier -> centres -> lists -> ...), three
+    // workgroups per CU deep, not a stream of instructions (profiles/r06d_phase_probe_cull.txt: 13 300 cycles per item on the clean
+    // field, 3 000 of them the staging); the full kernel, which is bound by instructions issued, gained nothing from the same
+    // prefetch in round 4.
+    float4 q_next = make_float4(0.f, 0.f, 0.f, 0.f);
+    int next_item = -1;   // the item q_next belongs to
     const ItemRange ir = my_items<RUNS>(P, total);
     for (int item = ir.first; item < ir.end; item += ir.step) {
         const int4 desc = P.items[item];
@@ -2158,8 +2194,8 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
             const int i = tid;
             const int p = cg * CULL_NPX + i;
             float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < tpad) q = P.rec[bk * P.cap + p];
-            s_raw[i] = q;
+            if (next_item == item) q = q_next;   // (workgroup-uniform) requested during the previous item
+            else if (p < tpad) q = P.rec[bk * P.cap + p];
             uint4* t = s_t + (i >> 5) * TILE_U4 + (i & 31);
             uint4 r0, r1, r2, r3;
             float mu;
@@ -2178,16 +2214,38 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
         }
         lds_barrier();
         PV_PHASE(0);
+        if (item + ir.step < ir.end) {   // the next item's record for this thread, if the next item is one of this kernel's
+            const int4 nd = P.items[item + ir.step];
+            if (item_culled(nd.y)) {     // (workgroup-uniform)
+                const int ntn = ctrl[nd.x * CTRL_STRIDE + C_TN];
+                const int np = nd.z * CULL_NPX + tid;
+                q_next = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (np < (ntn + PAD - 1) / PAD * PAD) q_next = P.rec[((size_t)nd.x * P.vn + item_kp(nd.y)) * P.cap + np];
+                next_item = item + ir.step;
+            }
+        }
 
         const int left = (tpad - cg * CULL_NPX + 31) >> 5;
         const int nti = left < 8 ? left : 8;
-        // ---- coarse pass: this wave's two pixel tiles against the 32 tile centres
-        for (int pt = wave * 2; pt < wave * 2 + 2; ++pt) {
+        // ---- coarse pass: this wave's two pixel tiles against the 32 tile centres (both MFMA pairs issued before either is consumed)
+        f32x16 cvd[2], cvc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pt = wave * 2 + u;
+            cvd[u] = zero;
+            cvc[u] = zero;
+            if (pt < nti) {   // wave-uniform
+                const bf16x8 Ad = __builtin_bit_cast(bf16x8, lbase[pt * TILE_U4]);
+                const bf16x8 Ac = __builtin_bit_cast(bf16x8, lbase[pt * TILE_U4 + 64]);
+                cvd[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ad, Bc, zero, 0, 0, 0);
+                cvc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac, Bc, zero, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pt = wave * 2 + u;
             if (pt >= nti) break;   // wave-uniform
-            const bf16x8 Ad = __builtin_bit_cast(bf16x8, lbase[pt * TILE_U4]);
-            const bf16x8 Ac = __builtin_bit_cast(bf16x8, lbase[pt * TILE_U4 + 64]);
-            const f32x16 vd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ad, Bc, zero, 0, 0, 0);
-            const f32x16 vc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac, Bc, zero, 0, 0, 0);
+            const f32x16 vd = cvd[u], vc = cvc[u];
             unsigned um = 0u;
             int nv = 0;
 #pragma unroll
@@ -2211,21 +2269,31 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
             if (nv) atomicAdd(&s_cv[col], nv);
             if (um) {
                 int at = atomicAdd(&s_nu[col], __popc(um));
-                uint16_t* const dst = s_list + col * CULL_NPX;
+                uint8_t* const dst = s_list + col * CULL_NPX;
                 while (um) {
                     const int r = __ffs((int)um) - 1;
                     um &= um - 1u;
-                    dst[at++] = (uint16_t)(pt * TILE_U4 + (r >> 2) * 8 + half * 4 + (r & 3));   // uint4 index of the first 16 bytes of the pixel's dt' row
+                    dst[at++] = (uint8_t)(pt * 32 + (r >> 2) * 8 + half * 4 + (r & 3));   // the pixel (accumulator row r of this half-wave)
                 }
             }
         }
         lds_barrier();
         PV_PHASE(1);   // (TIMED, this kernel: 0 staging, 1 coarse pass + barrier, 2 fine pass, 3 flush + cell list + re-evaluation + barriers)
         // ---- fine pass: the uncertain pixels of each of this wave's eight hypothesis tiles, gathered into groups of 32
+        // the wave's eight list lengths and certain-vote counts in four 16-byte reads (one wait) -- read one by one, each behind the
+        // store before it, they were a chain of sixteen LDS round trips per item: 3 600 cycles with nothing to score (r06d)
+        // (the lengths are wave-uniform: into SGPRs at once; the tile's certain votes -- the same for its 32 hypotheses -- join the
+        //  counters here, in ONE of the two half-waves that half_wave_sum2 joins)
+        int nu8[MH];
+        {
+            const int4 a0 = *reinterpret_cast<const int4*>(s_nu + wave * MH), a1 = *reinterpret_cast<const int4*>(s_nu + wave * MH + 4);
+            const int4 c0 = *reinterpret_cast<const int4*>(s_cv + wave * MH), c1 = *reinterpret_cast<const int4*>(s_cv + wave * MH + 4);
+            const int av[MH] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, cv[MH] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-        for (int t = 0; t < MH; ++t) {   // pad the wave's own lists to whole groups with the dead row (wave-local: LDS operations of a wave stay in order)
-            const int nu = s_nu[wave * MH + t];
-            if (lane < 32 && nu + lane < ((nu + 31) & ~31)) s_list[(wave * MH + t) * CULL_NPX + nu + lane] = (uint16_t)CULL_DEAD;
+            for (int t = 0; t < MH; ++t) {
+                nu8[t] = __builtin_amdgcn_readfirstlane(av[t]);
+                cnt[t] += half == 0 ? (unsigned)cv[t] * 0xFFFFu : 0u;
+            }
         }
         unsigned flg[MH];   // bit (groups - 1 - g) set = gathered group g of tile t holds a test inside the band
         float x0, x1, x2, x3, x4, x5, x6, x7, dmo;
@@ -2237,7 +2305,7 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
         for (int t = 0; t < MH; ++t) {
             flg[t] = 0u;
             const int j = wave * MH + t;
-            const int nu = __builtin_amdgcn_readfirstlane(s_nu[j]);
+            const int nu = nu8[t];
             const int ng = (nu + 31) >> 5;
             if (TIMED || (P.flags & PVNET_F_BAND_STATS)) {
                 st_steps += (unsigned)ng;
@@ -2247,16 +2315,23 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
                 // Software pipeline over the tile's gathered groups: a group's A rows are requested one trip ahead (list entry -> row
                 // address -> two 16-byte reads: a dependent LDS chain of ~200 cycles that would otherwise open every step) and the
                 // previous group's last 15 vote operations fill the wait for this group's MFMAs, as in the exact kernel.
-                const uint16_t* const lst = s_list + j * CULL_NPX + col;
-                const unsigned a0 = lst[0];
+                // lane `col` of group g takes list entry 32 g + col -- a pixel index; its A rows start at uint4 (pixel tile) * TILE_U4 +
+                // (row); beyond the list's end: the dead row (x = -4: no vote, no flag)
+                const uint8_t* const lst = s_list + j * CULL_NPX + col;
+                auto row_of = [&](int g) -> unsigned {
+                    const unsigned e = lst[g * 32];
+                    const unsigned a = ((e & 0xE0u) << 2) | (e & 31u);
+                    return g * 32 + col < nu ? a : (unsigned)CULL_DEAD;
+                };
+                const unsigned a0 = row_of(0);
                 uint4 Ra = s_t[a0 + half * 32], Rb = s_t[a0 + half * 32 + 64];
-                unsigned an = lst[ng > 1 ? 32 : 0];
+                unsigned an = row_of(ng > 1 ? 1 : 0);
                 {
                     const f32x16 va = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Ra), B[t], zero, 0, 0, 0);
                     const f32x16 vb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Rb), B[t], zero, 0, 0, 0);
                     Ra = s_t[an + half * 32];
                     Rb = s_t[an + half * 32 + 64];
-                    an = lst[(ng > 2 ? 2 : ng - 1) * 32];
+                    an = row_of(ng > 2 ? 2 : ng - 1);
                     __builtin_amdgcn_sched_barrier(0);
                     asm volatile("s_nop 11");   // (the votes are inline asm: the wait states are ours, tools/check_mfma_hazard.py)
                     vote_subs(PV_XS, PV_LO(va, vb));
@@ -2269,7 +2344,7 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
                     const f32x16 vb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Rb), B[t], zero, 0, 0, 0);
                     Ra = s_t[an + half * 32];        // (the last trip re-reads the last group: harmless)
                     Rb = s_t[an + half * 32 + 64];
-                    an = lst[(g + 2 < ng ? g + 2 : ng - 1) * 32];
+                    an = row_of(g + 2 < ng ? g + 2 : ng - 1);
                     __builtin_amdgcn_sched_barrier(0);
                     vote_slow_close(cnt[t], flg[t], acc, dmo, PV_XS);   // the previous group's last 15 operations fill the wait
                     asm volatile("s_nop 3");
@@ -2280,9 +2355,6 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
                 }
                 vote_slow_close(cnt[t], flg[t], acc, dmo, PV_XS);
             }
-            // the tile's certain votes: the same for its 32 hypotheses; added in ONE of the two half-waves that half_wave_sum2 joins
-            const unsigned cv = (unsigned)s_cv[j];
-            cnt[t] += half == 0 ? cv * 0xFFFFu : 0u;
         }
 #undef PV_XS
 #undef PV_LO
@@ -2327,8 +2399,8 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
                     m &= m - 1u;
                     const int slot = (ng - 1 - gb) * 32 + row;
                     if (slot < nu) {   // (beyond: the dead row)
-                        const unsigned a = s_list[j * CULL_NPX + slot];
-                        const float4 r = s_raw[(a >> 7) * 32 + (a & 31u)];
+                        const int px = cg * CULL_NPX + (int)s_list[j * CULL_NPX + slot];   // < tpad: rows beyond it are zero rows, never uncertain
+                        const float4 r = P.rec[bk * P.cap + px];
                         votes += inlier_literal(r.x, r.y, r.z, r.w, hv.x, hv.y, P.thresh) ? 1 : 0;
                         ++ntests;
                     }
@@ -2361,15 +2433,22 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
     }
 #undef PV_PHASE
 }
-#define PV_DEF_SCORE_CULL(TIMED_, RUNS_)                                                                                  \
-    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8), amdgpu_num_vgpr(68))) void                \
-        score_exact_kernel_cull_##TIMED_##_##RUNS_(VoteParams P) {                                                        \
-        score_cull_body<TIMED_ != 0, RUNS_ != 0>(P);                                                                      \
+// ONE launch for a call whose key-points K3 may split between the two scoring forms (P.cull = 2, the default where the layout supports
+// culling): every workgroup walks its work items twice -- the dense ones with the exact kernel's body, then the disc-culled ones.  A
+// second launch for the culled items cost 7.5 us on the stream and 10 % of the six-stream rate when NOTHING was culled (2 304
+// workgroups of 48 KB that read one descriptor each, profiles/r06f_stage_ab.txt), and a call split between two launches ran each
+// at part of the machine (256 us against 195 / 172 for either form alone, r06e); here an item costs what its form costs, wherever it is.
+#define PV_DEF_SCORE_BOTH(TIMED_, RUNS_, NVGPR_)                                                                          \
+    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8), amdgpu_num_vgpr(NVGPR_ / 2))) void        \
+        score_exact_kernel_both_##TIMED_##_##RUNS_(VoteParams P) {                                                        \
+        const bool met_culled = score_exact_body<8, 1, TIMED_ != 0, 1, RUNS_ != 0, true>(P);                              \
+        if (met_culled || TIMED_) score_cull_body<TIMED_ != 0, RUNS_ != 0, true>(P);   /* (TIMED: the closing stamps) */  \
     }
-PV_DEF_SCORE_CULL(0, 0) PV_DEF_SCORE_CULL(1, 0) PV_DEF_SCORE_CULL(0, 1) PV_DEF_SCORE_CULL(1, 1)
-#undef PV_DEF_SCORE_CULL
-constexpr size_t CULL_LDS_BYTES = 9 * TILE_U4 * sizeof(uint4) + CULL_NPX * sizeof(float4) + 4 * 8 * 64 * sizeof(unsigned) +
-                                  32 * CULL_NPX * sizeof(uint16_t) + CULL_NPX * sizeof(float) + 64 * sizeof(int);
+PV_DEF_SCORE_BOTH(0, 0, 120) PV_DEF_SCORE_BOTH(1, 0, 120) PV_DEF_SCORE_BOTH(0, 1, 128) PV_DEF_SCORE_BOTH(1, 1, 128)
+#undef PV_DEF_SCORE_BOTH
+constexpr size_t CULL_LDS_BYTES = 9 * TILE_U4 * sizeof(uint4) + 4 * 8 * 64 * sizeof(unsigned) +
+                                  32 * CULL_NPX * sizeof(uint8_t) + CULL_NPX * sizeof(float) + 64 * sizeof(int);
+static_assert(4 * (CULL_LDS_BYTES + 64) <= 160 * 1024, "four workgroups of the merged scoring kernel per CU");
 
 // ------------------------------------------------------------------------------------------------------------
 // Development aid (pvnet_vote_band_margin, tools/band_margin.py): the exactness argument of the exact mode, MEASURED.
@@ -3125,8 +3204,24 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
         if (wgs > max_items) wgs = max_items;
         if (wgs < 1) wgs = 1;
         if (score_grid) *score_grid = (int)wgs;
-        if (P.exact && P.cull == 1) {
-            // every key-point is disc-culled (PVNET_SCORE_CULL=1): no item is left for the full kernel
+        if (P.exact && P.cull) {
+            // key-points may be disc-culled (K3 decides; PVNET_SCORE_CULL=1: all of them): ONE launch scores both kinds of item
+            // (score_exact_kernel_both_*), with the dense kernel's registers, LDS and grid: 12 workgroups per CU queued for a batch
+            // alone (four resident, three rounds), 8 beside other batches
+            const bool conc = (P.flags & PVNET_F_CONCURRENT) != 0;
+            const bool runs = T.score_runs == 1 || (T.score_runs < 0 && conc);
+            long long w2 = T.wgs_per_cu >= 0 ? wgs : (long long)T.cus * (conc ? 8 : 12);
+            if (w2 > max_items) w2 = max_items;
+            if (w2 < 1) w2 = 1;
+            if (score_grid) *score_grid = (int)w2;
+            const dim3 g((unsigned)w2), t(256);
+            if (timed_score) {
+                if (runs) hipLaunchKernelGGL(score_exact_kernel_both_1_1, g, t, CULL_LDS_BYTES, s, P);
+                else hipLaunchKernelGGL(score_exact_kernel_both_1_0, g, t, CULL_LDS_BYTES, s, P);
+            } else {
+                if (runs) hipLaunchKernelGGL(score_exact_kernel_both_0_1, g, t, CULL_LDS_BYTES, s, P);
+                else hipLaunchKernelGGL(score_exact_kernel_both_0_0, g, t, CULL_LDS_BYTES, s, P);
+            }
         } else if (P.exact) {
             const int mh = P.wg_g * P.hpl / 2;
             const int npx = P.wg_s * P.chunk;
@@ -3192,23 +3287,6 @@ int launch_all(const VoteParams& P, hipStream_t s, hipEvent_t* ev, int stage_mas
             if (rc) return rc;
         }
         PV_LAUNCH_CHECK();
-        if (P.cull) {   // the key-points K3 marked (all of them: P.cull = 1): items carry the mark, the kernel skips the others
-            const bool conc = (P.flags & PVNET_F_CONCURRENT) != 0;
-            const bool runs = T.score_runs == 1 || (T.score_runs < 0 && conc);
-            long long w2 = T.wgs_per_cu >= 0 ? wgs : (long long)T.cus * 9;   // three resident workgroups per CU (48 KB of LDS each): three rounds
-            if (w2 > max_items) w2 = max_items;
-            if (w2 < 1) w2 = 1;
-            const bool timed_cull = timed_score && P.cull == 1;   // (the device-clock stamps of a timed launch belong to ONE kernel)
-            if (score_grid && P.cull == 1) *score_grid = (int)w2;
-            const dim3 g((unsigned)w2), t(256);
-            if (timed_cull) {
-                if (runs) hipLaunchKernelGGL(score_exact_kernel_cull_1_1, g, t, CULL_LDS_BYTES, s, P);
-                else hipLaunchKernelGGL(score_exact_kernel_cull_1_0, g, t, CULL_LDS_BYTES, s, P);
-            } else {
-                if (runs) hipLaunchKernelGGL(score_exact_kernel_cull_0_1, g, t, CULL_LDS_BYTES, s, P);
-                else hipLaunchKernelGGL(score_exact_kernel_cull_0_0, g, t, CULL_LDS_BYTES, s, P);
-            }
-        }
         PV_LAUNCH_CHECK();
     }
     PV_HIP(mark(5));
