@@ -69,7 +69,8 @@ constexpr int SEG_WORDS = 64;          // a segment = 64 words = 4096 pixels: th
 #define PVNET_SMALL_PRIO 3
 #endif
 #ifndef PVNET_CULL_Q_MILLI
-#define PVNET_CULL_Q_MILLI 250 // disc culling is selected for a key-point whose candidate intersections spread over <= 0.25 rho tan(theta0)
+#define PVNET_CULL_Q_MILLI 500 // a key-point votes for disc culling when its candidate intersections spread over <= 0.5 rho tan(theta0)
+                               // (profiles/r06k_cull_crossover.txt: culling wins up to a median q of 0.5 - 0.65)
 #endif
 #ifndef PVNET_CULL_DEFAULT
 #define PVNET_CULL_DEFAULT 2   // what PVNET_SCORE_CULL = -1 (not set) means: 0 = never, 1 = every key-point, 2 = the key-points K3 selects
@@ -155,6 +156,14 @@ struct VoteParams {
     uint4* hypc;         // [b][vn][hn_pad / 32][2] B column of every 32-hypothesis tile's CENTRE, scaled by 1 / (radius + band)
     float* hypg;         // [b][vn][hn_pad / 32]    g = radius term / (radius term + band term) of the tile (0: every pixel uncertain)
 };
+
+// per-call flags: int32 [8] behind the culling marks.  CF_ANY_CULLED: some image of this call is disc-culled -- zeroed by K2 (the block of
+// image 0's last segment), set by K3's plan blocks, read by the merged scoring launch, whose workgroups enter the culling body only then
+// (a call without culled key-points pays one scalar load for the merged launch)
+constexpr int CF_ANY_CULLED = 0;
+__device__ __forceinline__ int32_t* call_flags_ptr(const VoteParams& P) {
+    return P.ctrl + (size_t)(P.b + 1) * CTRL_STRIDE + 3 * (size_t)P.b * P.vn;
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // arithmetic shared by several kernels
@@ -792,6 +801,7 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
                 P.ctrl[bi * CTRL_STRIDE + C_TN0] = tn0;
                 P.ctrl[bi * CTRL_STRIDE + C_TN] = tn;
                 P.ctrl[bi * CTRL_STRIDE + C_STATUS] = total > usable ? PVNET_S_OVERFLOW : 0;
+                if (bi == 0) call_flags_ptr(P)[CF_ANY_CULLED] = 0;   // (K3 sets it)
             }
         }
         const int tpad = (tn + PAD - 1) / PAD * PAD;  // sentinel records: zero direction never votes
@@ -844,6 +854,7 @@ __device__ __forceinline__ void plan_image(const VoteParams& P, int bi, bool cul
         P.ctrl[bi * CTRL_STRIDE + C_OX] = pm % P.w;
         P.ctrl[bi * CTRL_STRIDE + C_OY] = pm / P.w;
         if (!nch) P.ctrl[bi * CTRL_STRIDE + C_STATUS] |= PVNET_S_SKIPPED;
+        if (culled && n > 0) call_flags_ptr(P)[CF_ANY_CULLED] = 1;   // (zeroed by K2; every writer writes the same)
         if (bi == P.b - 1) {
             P.ctrl[P.b * CTRL_STRIDE] = base + n;  // total number of work items
             P.ctrl[P.b * CTRL_STRIDE + 6] = P.layout_fp;  // which layout the offsets of this workspace follow (epilogues check)
@@ -1015,6 +1026,32 @@ __device__ __forceinline__ uint32_t lane_xor(uint32_t v, int m) {
 #else
 #define PV_K3_STAMP(i) do { } while (0)
 #endif
+// the two pixels of draw i = h vn + k of image bi (ransac_voting_gpu.py:547: one [hn, vn, 2] draw per image; or the caller's idxs)
+__device__ __forceinline__ void draw_pair(const VoteParams& P, int bi, int i, int tn, int& t0, int& t1) {
+    if (P.idxs) {
+        t0 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2];
+        t1 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2 + 1];
+        t0 = t0 < 0 ? 0 : (t0 >= tn ? tn - 1 : t0);  // memory safety only; valid idxs are untouched
+        t1 = t1 < 0 ? 0 : (t1 >= tn ? tn - 1 : t1);
+    } else {
+        const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_HYP, (uint32_t)(P.image_base + bi));
+        t0 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u), (uint32_t)tn);
+        t1 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u + 1u), (uint32_t)tn);
+    }
+}
+// records of the cull block's hypothesis h = e NT + tid (zero records beyond hn)
+__device__ __forceinline__ void cull_block_load(const VoteParams& P, int bi, int k, int tn, int e, float4& qa, float4& qb) {
+    const int h = e * 256 + (int)threadIdx.x;
+    qa = qb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (h < P.hn) {
+        int t0, t1;
+        draw_pair(P, bi, h * P.vn + k, tn, t0, t1);
+        qa = P.rec[((size_t)bi * P.vn + k) * P.cap + t0];
+        qb = P.rec[((size_t)bi * P.vn + k) * P.cap + t1];
+    }
+}
+// (requesting the first records before the preamble -- the block is one chain of dependent waits -- gained nothing for a culled call
+//  and cost a call without culled key-points 0.5 us: r06l)
 __device__ __forceinline__ void cull_block(const VoteParams& P, int bi, int k, int tn, const KpShared& S, float2* s_h, uint32_t* s_key,
                                            long long k3_t0) {
     constexpr int NT = 256, E = CULL_HN / NT;
@@ -1027,39 +1064,24 @@ __device__ __forceinline__ void cull_block(const VoteParams& P, int bi, int k, i
     PV_K3_STAMP(0);   // preamble done
     const float rho = band_rho(tn);
     const float ox = (float)S.org[k * 2], oy = (float)S.org[k * 2 + 1];
-    // ---- this key-point's hypotheses (kernel.cu:11-49), caller order: thread t takes h = t, t + 256, ...; two hypotheses (four
-    //      record loads) in flight per thread
-#pragma unroll
-    for (int e0 = 0; e0 < E; e0 += 2) {
-        float4 qa[2], qb[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int h = (e0 + u) * NT + tid;
-            qa[u] = qb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (h < P.hn) {
-                const int i = h * P.vn + k;   // the draw's index in the reference's [hn, vn, 2] layout
-                int t0, t1;
-                if (P.idxs) {
-                    t0 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2];
-                    t1 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2 + 1];
-                    t0 = t0 < 0 ? 0 : (t0 >= tn ? tn - 1 : t0);  // memory safety only; valid idxs are untouched
-                    t1 = t1 < 0 ? 0 : (t1 >= tn ? tn - 1 : t1);
-                } else {
-                    const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_HYP, (uint32_t)(P.image_base + bi));
-                    t0 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u), (uint32_t)tn);
-                    t1 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u + 1u), (uint32_t)tn);
-                }
-                qa[u] = P.rec[bk * P.cap + t0];
-                qb[u] = P.rec[bk * P.cap + t1];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int h = (e0 + u) * NT + tid;
+    // ---- this key-point's hypotheses (kernel.cu:11-49), caller order: thread t takes h = t, t + 256, ...; two pairs of records in
+    //      flight at a time (three do not fit the kernel's 40 registers), the next requested as soon as a pair has been consumed
+    static_assert(E == 4, "cull_block: four hypotheses per thread");
+    {
+        auto put = [&](int h, const float4& a, const float4& b) {
             float hx = 0.f, hy = 0.f;
-            if (h < P.hn) hyp_intersect(qa[u].z, qa[u].w, qa[u].x, qa[u].y, qb[u].z, qb[u].w, qb[u].x, qb[u].y, hx, hy);
+            if (h < P.hn) hyp_intersect(a.z, a.w, a.x, a.y, b.z, b.w, b.x, b.y, hx, hy);
             s_h[h] = make_float2(hx, hy);
-        }
+        };
+        float4 qa[2], qb[2];
+        cull_block_load(P, bi, k, tn, 0, qa[0], qb[0]);
+        cull_block_load(P, bi, k, tn, 1, qa[1], qb[1]);
+        put(tid, qa[0], qb[0]);
+        cull_block_load(P, bi, k, tn, 2, qa[0], qb[0]);
+        put(NT + tid, qa[1], qb[1]);
+        cull_block_load(P, bi, k, tn, 3, qa[1], qb[1]);
+        put(2 * NT + tid, qa[0], qb[0]);
+        put(3 * NT + tid, qa[1], qb[1]);
     }
     PV_K3_STAMP(1);   // hypotheses
     // ---- sort keys: position on a Hilbert curve of 1/8-pixel cells about the origin (11 bits per coordinate: +-128 px); far and
@@ -1235,16 +1257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(20))) void hypo
     float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
     if (blk < nbd && live && i < P.hn * P.vn) {
         int t0, t1;
-        if (P.idxs) {
-            t0 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2];
-            t1 = P.idxs[((size_t)bi * P.hn * P.vn + i) * 2 + 1];
-            t0 = t0 < 0 ? 0 : (t0 >= tn ? tn - 1 : t0);  // memory safety only; valid idxs are untouched
-            t1 = t1 < 0 ? 0 : (t1 >= tn ? tn - 1 : t1);
-        } else {
-            const uint32_t key = pvnet_rng_key(P.seed, PVNET_TAG_HYP, (uint32_t)(P.image_base + bi));
-            t0 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u), (uint32_t)tn);
-            t1 = (int)pvnet_rng_below(pvnet_rng_at(key, (uint32_t)i * 2u + 1u), (uint32_t)tn);
-        }
+        draw_pair(P, bi, i, tn, t0, t1);
         q0 = P.rec[((size_t)bi * P.vn + hk) * P.cap + t0];  // (x, y, direction) of the two pixels
         q1 = P.rec[((size_t)bi * P.vn + hk) * P.cap + t1];
     }
@@ -1750,10 +1763,9 @@ constexpr float BAND_CLEAN = 1.0f;     // a cell whose minimum |a'|, |b'| reache
 //           mapping itself: a launch of strided items ends more evenly) -- so it is what calls flagged PVNET_F_CONCURRENT run.
 // HEAD (round 6): the body is the FIRST of the two a merged launch runs (score_exact_both_kernel: the dense items here, the
 //           disc-culled ones in score_cull_body behind it) -- the kernel's register allocation and its closing clock stamps are
-//           the second body's.  Returns whether the workgroup met a disc-culled item on its walk (workgroup-uniform): the second body
-//           is only entered then, so a call without culled key-points pays one compare per item for the merged launch.
+//           the second body's.
 template <int MH, int FOLD, bool TIMED, int NACC, bool RUNS_, bool HEAD = false>
-__device__ __forceinline__ bool score_exact_body(VoteParams P) {
+__device__ __forceinline__ void score_exact_body(VoteParams P) {
     if (HEAD) { }
     else if (MH == 8 && NACC == 2) PVNET_SPARE_VGPRS(167);
     else if (MH == 8 && RUNS_) PVNET_SPARE_VGPRS(135);
@@ -1814,14 +1826,10 @@ __device__ __forceinline__ bool score_exact_body(VoteParams P) {
 #pragma unroll
         for (int t = 0; t < MH; ++t) cnt[t] = 0u;
     };
-    bool met_culled = false;
     const ItemRange ir = my_items<RUNS>(P, total);
     for (int item = ir.first; item < ir.end; item += ir.step) {
         const int4 desc = P.items[item];
-        if (item_culled(desc.y)) {   // (workgroup-uniform) a key-point the disc-culling body scores
-            met_culled = true;
-            continue;
-        }
+        if (item_culled(desc.y)) continue;   // (workgroup-uniform) a key-point the disc-culling body scores
         const int bi = desc.x, k = item_kp(desc.y), cg = desc.z, hq = desc.w;
         const int tn = ctrl[bi * CTRL_STRIDE + C_TN];
         const float rho = band_rho(tn);
@@ -2037,7 +2045,6 @@ __device__ __forceinline__ bool score_exact_body(VoteParams P) {
         }
     }
 #undef PV_PHASE
-    return met_culled;
 }
 // The register allocator fills whatever budget the occupancy target leaves (3 waves per SIMD: up to 168 VGPRs), the library needs
 // the top granule of every allocation unused (PVNET_SPARE_VGPRS): amdgpu_num_vgpr -- a literal, hence one definition per
@@ -2080,13 +2087,17 @@ PV_DEF_SCORE_EXACT4(8, 1, 1, 128) PV_DEF_SCORE_EXACT4(8, 2, 1, 160)
 // ------------------------------------------------------------------------------------------------------------
 // TAIL (round 6): the second body of a merged launch (the dense items were scored by score_exact_body<..., HEAD> before it, which also
 //           took the opening clock stamp)
-template <bool TIMED, bool RUNS, bool TAIL = false>
+// Items are always STRIDED over the workgroups here, whatever the dense body's mapping: contiguous runs (B columns and counters kept
+// while the key-point stays) cost this body 27 % on the clean field (55 -> 70 us, r06k) -- its items are chains of waits, and a run
+// puts the long ones of one key-point into one workgroup.  WIDE: the kernel allocates 136 VGPRs (the dense body runs contiguous
+// runs: batches in flight), else 128.
+template <bool TIMED, bool TAIL, bool WIDE>
 __device__ __forceinline__ void score_cull_body(VoteParams P) {
     constexpr int MH = 8;
     // the merged kernel's allocation is the dense kernel's of the same item mapping: 136 VGPRs for contiguous runs (batches in flight: what
     // is left of the SIMD's 512 holds other streams' small stages -- at 144 the six-stream rate fell 2.8 %, r06g), 128 for a batch
     // alone (four waves per SIMD, four workgroups of 40 KB per CU).  This body spills a few per-item constants to fit.
-    if (RUNS) PVNET_SPARE_VGPRS(135); else PVNET_SPARE_VGPRS(127);
+    if (WIDE) PVNET_SPARE_VGPRS(135); else PVNET_SPARE_VGPRS(127);
     unsigned long long* __restrict__ stamps = reinterpret_cast<unsigned long long*>(P.pix);
     if (TIMED && !TAIL && threadIdx.x == 0) stamps[2 * blockIdx.x] = (unsigned long long)wall_clock64();
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2125,9 +2136,6 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
     unsigned cnt[MH];   // packed-norm vote counters (votes_of_norm): fine votes of the clean cells + the certain votes
 #pragma unroll
     for (int t = 0; t < MH; ++t) cnt[t] = 0u;
-    long long run_key = -1;
-    int run_h0 = 0, run_items = 0;
-    size_t run_bk = 0;
     unsigned st_steps = 0u, st_full = 0u;   // PVNET_F_BAND_STATS: fine steps executed / steps the exact kernel would execute (this wave)
     auto flush_counts = [&](size_t fbk, int fh0) {
         int32_t* const pc = P.cnts + fbk * P.hn_pad + fh0;
@@ -2149,7 +2157,7 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
     // prefetch in round 4.
     float4 q_next = make_float4(0.f, 0.f, 0.f, 0.f);
     int next_item = -1;   // the item q_next belongs to
-    const ItemRange ir = my_items<RUNS>(P, total);
+    const ItemRange ir = my_items<false>(P, total);
     for (int item = ir.first; item < ir.end; item += ir.step) {
         const int4 desc = P.items[item];
         if (!item_culled(desc.y)) continue;   // (workgroup-uniform) a key-point the full exact kernel scores
@@ -2162,10 +2170,8 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
         const int tpad = (tn + PAD - 1) / PAD * PAD;
         const int hslice = hq * 4 * MH * 32;
         const int h0 = hslice + wave * MH * 32;
-        const long long key = (long long)bk * (P.hgroups / P.wg_g) + hq;
-        // a run's counters hold < 65536 votes per half: per item and lane pair at most 16 fine votes per group (8 groups) and the
-        // certain votes of the item's 256 pixels -- 384: a run is cut after 160 items
-        const bool fresh = !RUNS || key != run_key || run_items >= 160;
+        // (the counters hold < 65536 votes per half: per item and lane pair at most 16 fine votes per group (8 groups) and the certain
+        //  votes of the item's 256 pixels -- 384)
 
         lds_barrier();  // the previous item's tiles, lists and cells have been consumed
         PV_PHASE(3);
@@ -2173,12 +2179,7 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
         if (threadIdx.x < 64) s_nu[threadIdx.x] = 0;   // s_nu and s_cv
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        if (fresh) {
-            if (RUNS && run_key >= 0) flush_counts(run_bk, run_h0);
-            run_key = key;
-            run_bk = bk;
-            run_h0 = h0;
-            run_items = 0;
+        {
             const int c2 = tid & 31, h2 = (tid >> 5) & 1;
 #pragma unroll
             for (int t = 0; t < MH; ++t) {
@@ -2189,7 +2190,6 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
             gcol = P.hypg[bk * ntl + hq * 32 + c2];
             tile_live = hslice + c2 * 32 < P.hn;
         }
-        ++run_items;
         {   // thread = pixel: its A rows, its raw record, its 1 - mu
             const int i = tid;
             const int p = cg * CULL_NPX + i;
@@ -2363,7 +2363,7 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
         int colx = col;
         asm volatile("" : "+v"(colx));
         const bool padded = h0 + MH * 32 > P.hn;
-        if (!RUNS) flush_counts(bk, h0);
+        flush_counts(bk, h0);
 #pragma unroll
         for (int t = 0; t < MH; ++t) {
             unsigned mask = flg[t];
@@ -2417,7 +2417,6 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
             }
         }
     }
-    if (RUNS && run_key >= 0) flush_counts(run_bk, run_h0);
     if ((P.flags & PVNET_F_BAND_STATS) && lane == 0) {   // development aid: how much of the exact kernel's work was left
         atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 1, (int)st_steps);
         atomicAdd(P.ctrl + P.b * CTRL_STRIDE + 7, (int)st_full);
@@ -2441,8 +2440,9 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
 #define PV_DEF_SCORE_BOTH(TIMED_, RUNS_, NVGPR_)                                                                          \
     __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8), amdgpu_num_vgpr(NVGPR_ / 2))) void        \
         score_exact_kernel_both_##TIMED_##_##RUNS_(VoteParams P) {                                                        \
-        const bool met_culled = score_exact_body<8, 1, TIMED_ != 0, 1, RUNS_ != 0, true>(P);                              \
-        if (met_culled || TIMED_) score_cull_body<TIMED_ != 0, RUNS_ != 0, true>(P);   /* (TIMED: the closing stamps) */  \
+        const int any_culled = call_flags_ptr(P)[CF_ANY_CULLED];   /* (scalar load, long back when it is needed) */       \
+        score_exact_body<8, 1, TIMED_ != 0, 1, RUNS_ != 0, true>(P);                                                      \
+        if (any_culled || TIMED_) score_cull_body<TIMED_ != 0, true, RUNS_ != 0>(P);   /* (TIMED: the closing stamps) */  \
     }
 PV_DEF_SCORE_BOTH(0, 0, 120) PV_DEF_SCORE_BOTH(1, 0, 120) PV_DEF_SCORE_BOTH(0, 1, 128) PV_DEF_SCORE_BOTH(1, 1, 128)
 #undef PV_DEF_SCORE_BOTH
@@ -3437,8 +3437,8 @@ int pvnet_vote_layout(int b, int h, int w, int vn, int hn, int max_num, PvnetVot
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     L->nseg = (L->words + SEG_WORDS - 1) / SEG_WORDS;
     // ctrl rows [b + 1][8], then the exact mode's band origins int32 [b][vn][2] (band_origin_ptr()), then which key-points are
-    // disc-culled int32 [b][vn] (kp_cull_ptr())
-    L->off_ctrl = take(sizeof(int32_t) * (CTRL_STRIDE * (size_t)(b + 1) + 3 * (size_t)b * vn));
+    // disc-culled int32 [b][vn] (kp_cull_ptr()), then the call's flags int32 [8] (call_flags_ptr())
+    L->off_ctrl = take(sizeof(int32_t) * (CTRL_STRIDE * (size_t)(b + 1) + 3 * (size_t)b * vn + 8));
     // [2][b][nseg] int32 (the second array holds the mask's segment counts; the first is unused since round 2), then,
     // when thinning is possible (max_num < h*w), the segments' cumulative histograms uint16 [b][nseg][THIN_BINS]
     L->off_seg = take(align_up(sizeof(int32_t) * 2 * (size_t)b * L->nseg, 16) +
