@@ -1983,17 +1983,30 @@ __device__ __forceinline__ void score_exact_body(VoteParams P) {
             for (int t = 0; t < MH; ++t) cnt[t] = dmn[t] >= BAND_CLEAN ? cnt[t] : 0u;  // a flagged cell's votes are discarded
         }
         if (!RUNS) flush_counts(bk, h0);  // (RUNS: when the run ends)
+        // (round 6: ONE slot reservation per wave and item -- the eight ballots and their popcounts are scalar work, the wave's
+        //  cells go behind one LDS atomic; one reservation per hypothesis tile, most of them taken, cost ~70 vector operations more)
+        unsigned long long bal[MH];
+        int ncw = 0;
 #pragma unroll
         for (int t = 0; t < MH; ++t) {
             unsigned mask = FOLD ? flg[t] : (dmn[t] >= BAND_CLEAN ? 0u : all_groups);
             if (padded && h0 + t * 32 + colx >= P.hn) mask = 0u;  // padding columns of the last slice: nobody reads their counts
-            const unsigned long long bal = __ballot(mask != 0u);
-            if (bal) {  // wave-uniform
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_ncell, __popcll(bal));
-                base = __builtin_amdgcn_readfirstlane(base);
-                const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                if (mask != 0u) s_cells[slot] = (unsigned)(wave * MH * 32 + t * 32 + colx) | ((unsigned)half << 10) | (mask << 11);
+            flg[t] = mask;
+            bal[t] = __ballot(mask != 0u);
+            ncw += (int)__popcll(bal[t]);
+        }
+        if (ncw) {  // wave-uniform
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_ncell, ncw);
+            base = __builtin_amdgcn_readfirstlane(base);
+            const unsigned cell0 = (unsigned)(wave * MH * 32 + colx) | ((unsigned)half << 10);
+#pragma unroll
+            for (int t = 0; t < MH; ++t) {
+                if (bal[t]) {  // wave-uniform
+                    const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal[t] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[t], 0u));
+                    if (flg[t] != 0u) s_cells[slot] = (cell0 + (unsigned)(t * 32)) | (flg[t] << 11);
+                    base += (int)__popcll(bal[t]);
+                }
             }
         }
         lds_barrier();
@@ -2364,17 +2377,26 @@ __device__ __forceinline__ void score_cull_body(VoteParams P) {
         asm volatile("" : "+v"(colx));
         const bool padded = h0 + MH * 32 > P.hn;
         flush_counts(bk, h0);
+        unsigned long long bal[MH];   // (one slot reservation per wave and item, as in the dense body)
+        int ncw = 0;
 #pragma unroll
         for (int t = 0; t < MH; ++t) {
-            unsigned mask = flg[t];
-            if (padded && h0 + t * 32 + colx >= P.hn) mask = 0u;   // padding columns: nobody reads their counts
-            const unsigned long long bal = __ballot(mask != 0u);
-            if (bal) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_ncell, __popcll(bal));
-                base = __builtin_amdgcn_readfirstlane(base);
-                const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                if (mask != 0u) s_cells[slot] = (unsigned)(wave * MH * 32 + t * 32 + colx) | ((unsigned)half << 10) | (mask << 11);
+            if (padded && h0 + t * 32 + colx >= P.hn) flg[t] = 0u;   // padding columns: nobody reads their counts
+            bal[t] = __ballot(flg[t] != 0u);
+            ncw += (int)__popcll(bal[t]);
+        }
+        if (ncw) {  // wave-uniform
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_ncell, ncw);
+            base = __builtin_amdgcn_readfirstlane(base);
+            const unsigned cell0 = (unsigned)(wave * MH * 32 + colx) | ((unsigned)half << 10);
+#pragma unroll
+            for (int t = 0; t < MH; ++t) {
+                if (bal[t]) {  // wave-uniform
+                    const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal[t] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[t], 0u));
+                    if (flg[t] != 0u) s_cells[slot] = (cell0 + (unsigned)(t * 32)) | (flg[t] << 11);
+                    base += (int)__popcll(bal[t]);
+                }
             }
         }
         lds_barrier();
