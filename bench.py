@@ -85,7 +85,9 @@ N_SIMD = 256 * 4
 N_XCD = 8
 SCORE_KERNEL = "score_exact_kernel"
 PATH_KERNELS = ("mask_bits_kernel", "compact_kernel", "hypothesis_kernel", SCORE_KERNEL, "select_refine_kernel")
-KERNEL_SOURCES = ("pvnet_amd/csrc/pvnet_vote.hip", "pvnet_amd/csrc/pvnet_rng.h", "include/pvnet_vote.h")
+KERNEL_SOURCES = tuple("pvnet_amd/csrc/" + f for f in (
+    "vote_common.h", "k1_mask.hip", "k2_compact.hip", "k3_hypotheses.hip", "k4_score_valu.hip", "k4_score_mfma.hip", "k4_exact_body.h",
+    "k4_score_exact.hip", "k4_score_cull.hip", "k5_refine.hip", "epilogues.hip", "vote_host.hip", "pvnet_rng.h")) + ("include/pvnet_vote.h",)
 
 
 def parse(argv=None):

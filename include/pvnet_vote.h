@@ -84,6 +84,12 @@ extern "C" {
                                       The Python front end sets it when consecutive calls alternate streams
                                       (voting.concurrent_hint; concurrent=True / False decide explicitly). */
 
+#define PVNET_F_CULL_ALL   512u    /* exact mode: score EVERY key-point with disc culling where the layout supports it (batch shapes with
+                                      256-pixel work items, 1 024 hypotheses, at most 32 key-points); */
+#define PVNET_F_CULL_NONE 1024u    /* ... or none.  Neither flag (the default): K3 selects per image on the device from the spread of
+                                      eight candidate intersections per key-point (profiles/r06k_cull_crossover.txt).  The inlier counts
+                                      are the same integers under every selection; only the time differs (tests / probes use the flags) */
+
 /* per-(image,key-point) status bits written to out_status */
 #define PVNET_S_SKIPPED   1        /* fewer than min_num foreground pixels (or none kept): zeros returned */
 #define PVNET_S_SINGULAR  2        /* normal matrix singular: winning hypothesis returned (reference raises) */
@@ -123,7 +129,7 @@ typedef struct PvnetVoteLayout {
     int32_t nseg;           /* ceil(words / 64)                                                             */
     int32_t wg_g, wg_s;     /* a scoring workgroup covers wg_g hypothesis groups x wg_s chunks (wg_g*wg_s=4) */
     int32_t reserved_;      /* 1: fast mode scores on the matrix pipe (score_mfma_kernel), 0: VALU kernel                */
-    /* ABI 8 / 9 -- disc culling of the exact mode (pvnet_vote.hip: cull_block of hypothesis_kernel / score_exact_kernel_cull).
+    /* ABI 8 / 9 -- disc culling of the exact mode (k3_hypotheses.hip: cull_block of hypothesis_kernel; k4_score_cull.hip: score_exact_kernel_both).
      * Empty (cull = 0) unless the layout scores 8 hypothesis tiles per wave on 256-pixel work items with hn_pad = 1024 and
      * vn <= 32.  Which key-points of a call ARE culled is decided on the device per (image, key-point) -- from the spread of
      * the candidate intersections of the band-origin estimate (PVNET_SCORE_CULL: 2 = that, the default; 1 = all; 0 = none) --

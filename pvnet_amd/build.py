@@ -7,17 +7,23 @@ hipcc cross-compiles without a GPU.  The library lands next to this file so that
 from __future__ import annotations
 
 import os
+import re
 import shutil
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", "pvnet_vote.hip"), os.path.join(HERE, "csrc", "pvnet_nn.hip"),
-       os.path.join(HERE, "csrc", "pvnet_rccl.hip")]   # (the last one is host code only: the RCCL binding)
-DEPS = SRC + [os.path.join(HERE, "csrc", "pvnet_rng.h"), os.path.join(ROOT, "include", "pvnet_vote.h"),
-              os.path.join(ROOT, "include", "pvnet_nn.h")]
-LIB = os.path.join(HERE, "libpvnet_vote.so")
+CSRC = os.path.join(HERE, "csrc")
+# one translation unit per stage (the map is at the top of vote_host.hip); pvnet_rccl.hip is host code only: the RCCL binding
+VOTE_TU = ["k1_mask.hip", "k2_compact.hip", "k3_hypotheses.hip", "k4_score_valu.hip", "k4_score_mfma.hip", "k4_score_exact.hip",
+           "k4_score_cull.hip", "k5_refine.hip", "epilogues.hip", "vote_host.hip"]
+SRC = [os.path.join(CSRC, f) for f in VOTE_TU + ["pvnet_nn.hip", "pvnet_rccl.hip"]]
+DEPS = SRC + [os.path.join(CSRC, "vote_common.h"), os.path.join(CSRC, "k4_exact_body.h"), os.path.join(CSRC, "pvnet_rng.h"),
+              os.path.join(ROOT, "include", "pvnet_vote.h"), os.path.join(ROOT, "include", "pvnet_nn.h")]
+LIB = os.path.join(HERE, "libpvnet_vote.so")          # release: the knobs are constants, the kernels the defaults reach
+DEV_LIB = os.path.join(HERE, "libpvnet_vote_dev.so")  # -DPVNET_DEV: environment knobs + every kernel variant (knob tests, fuzz, tuning tools)
+OBJ_DIR = os.path.join(HERE, "build")
 ARCH = "gfx950"
 # host-side pose refinement (plain C++, g++): include/pvnet_pnp.h
 PNP_SRC = os.path.join(HERE, "csrc", "pvnet_pnp.cpp")
@@ -39,8 +45,41 @@ def flags():
             "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-Wall"]
 
 
-def up_to_date() -> bool:
-    return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS)
+def up_to_date(lib=None) -> bool:
+    lib = lib or LIB
+    return os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(d) for d in DEPS)
+
+
+def compile_link(out: str, dev: bool, verbose: bool = False) -> None:
+    """every translation unit to an object file (in parallel: the exact-mode scoring kernels dominate), then one link"""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    cflags = [f for f in flags() if f != "-shared"] + (["-DPVNET_DEV"] if dev else [])
+    objs = [os.path.join(OBJ_DIR, os.path.basename(src) + (".dev.o" if dev else ".o")) for src in SRC]
+
+    def one(job):
+        src, obj = job
+        cmd = [hipcc_path()] + cflags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    # vote_host.hip last: pvnet_vote_build_info() reports how many kernels the library holds, counted in the other objects
+    # (kernel descriptor symbols `<name>.kd` of their device code)
+    jobs = [(src, obj) for src, obj in zip(SRC, objs) if not src.endswith("vote_host.hip")]
+    with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 4) - 1))) as ex:
+        list(ex.map(one, jobs))
+    names = set()
+    for _, obj in jobs:
+        names.update(re.findall(rb"[\w$.]+\.kd(?=\x00)", open(obj, "rb").read()))
+    cflags.append(f"-DPVNET_KERNEL_COUNT={len(names)}")
+    for src, obj in zip(SRC, objs):
+        if src.endswith("vote_host.hip"):
+            one((src, obj))
+    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
 
 
 def build_pnp(force: bool = False, verbose: bool = False) -> str:
@@ -145,15 +184,21 @@ def check_resources() -> None:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     build_pnp(force, verbose)
-    if force or not up_to_date():
+    fresh = force or not up_to_date(LIB)
+    if fresh:
         tmp = LIB + ".new"
-        cmd = [hipcc_path()] + flags() + SRC + ["-o", tmp]
-        if verbose:
-            print(" ".join(cmd))
         try:
-            subprocess.check_call(cmd)
+            compile_link(tmp, dev=False, verbose=verbose)
             check_resources()
             os.replace(tmp, LIB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+    if force or not up_to_date(DEV_LIB):
+        tmp = DEV_LIB + ".new"
+        try:
+            compile_link(tmp, dev=True, verbose=verbose)
+            os.replace(tmp, DEV_LIB)
         finally:
             if os.path.exists(tmp):
                 os.remove(tmp)

@@ -23,7 +23,7 @@
 
 namespace {
 
-// one unused VGPR granule beyond what a kernel uses: see PVNET_SPARE_VGPRS in pvnet_vote.hip
+// one unused VGPR granule beyond what a kernel uses: see PVNET_SPARE_VGPRS in vote_common.h
 #define PVNET_SPARE_VGPRS_(r) asm volatile("" ::: "v" #r)
 #define PVNET_SPARE_VGPRS(r) PVNET_SPARE_VGPRS_(r)
 constexpr int NN_T = 256;  // queries per workgroup = reference points per LDS tile

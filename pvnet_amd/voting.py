@@ -7,7 +7,7 @@ Mirrors (same names, argument meaning, defaults and error behaviour):
   exported by the pybind module ``ransac_voting`` (:102-107)
 
 PyTorch is plumbing only here: device memory, the current stream, dtype/stride bookkeeping.  All compute is
-in ``libpvnet_vote.so`` (pvnet_amd/csrc/pvnet_vote.hip, C ABI in include/pvnet_vote.h) reached through ctypes
+in ``libpvnet_vote.so`` (pvnet_amd/csrc/*.hip -- the stage map is at the top of vote_host.hip -- C ABI in include/pvnet_vote.h) reached through ctypes
 (which releases the GIL for the duration of the call).  There is NO CPU fallback: without the library, or with
 CPU tensors, these functions raise ``RuntimeError`` exactly like the reference's ``CHECK_CUDA`` does
 (src/ransac_voting.cpp:7-9).
@@ -22,7 +22,13 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpvnet_vote.so")
+LIB_PATH = os.path.join(_HERE, "libpvnet_vote.so")          # release build: the tuning knobs are constants
+DEV_LIB_PATH = os.path.join(_HERE, "libpvnet_vote_dev.so")  # development build (-DPVNET_DEV): PVNET_* environment knobs + every kernel variant
+# the knobs of the development build (vote_host.hip, load_tuning): with one of them in the environment the Python front end loads
+# libpvnet_vote_dev.so instead of the release library -- the knob tests, the fuzz matrix and the tuning tools work through that
+TUNING_KNOBS = ("PVNET_SCORE_MODE", "PVNET_SCORE_WGS_PER_CU", "PVNET_SCORE_HPL", "PVNET_SCORE_CHUNK", "PVNET_COMPACT_KG",
+                "PVNET_SCORE_XCD", "PVNET_SCORE_ATOMIC", "PVNET_SCORE_LDS_KB", "PVNET_SCORE_ACC", "PVNET_EXACT_FOLD",
+                "PVNET_SCORE_RUNS", "PVNET_SCORE_CULL", "PVNET_CULL_Q_MILLI", "PVNET_DEV_STAGES")
 
 F_LITERAL = 1
 F_NO_REFINE = 2
@@ -30,6 +36,7 @@ F_VERTEX_F16, F_VERTEX_BF16, F_LOGITS_F16, F_LOGITS_BF16 = 4, 8, 16, 32
 F_APPROX = 64        # the round-1/2 "fast" mode: matrix-pipe scoring without the rounding-band re-evaluation
 F_BAND_STATS = 128   # development aid: count the re-evaluated cells / literal tests (exact mode)
 F_CONCURRENT = 256   # hint: other batches are in flight on other streams (see concurrent_hint)
+F_CULL_ALL, F_CULL_NONE = 512, 1024   # exact mode: disc-cull every key-point / none (default: K3 selects per image on the device)
 S_SKIPPED, S_SINGULAR, S_NO_INLIER, S_OVERFLOW = 1, 2, 4, 8
 NUM_STAGES = 6
 STAGE_NAMES = ("mask_bits", "subsample", "compact", "hypotheses", "score", "select_refine")
@@ -47,14 +54,28 @@ class Layout(C.Structure):
 
 
 _lib = None
+_libs = {}   # path -> loaded library
+
+
+def _wanted_library() -> str:
+    if os.environ.get("PVNET_VOTE_LIB"):   # development aid: an experimental build of the same ABI
+        return os.environ["PVNET_VOTE_LIB"]
+    return DEV_LIB_PATH if any(os.environ.get(k) not in (None, "") for k in TUNING_KNOBS) else LIB_PATH
 
 
 def load_library() -> C.CDLL:
-    """dlopen the in-tree HIP library; loud failure if it has not been built (python -m pvnet_amd.build)."""
+    """dlopen the in-tree HIP library; loud failure if it has not been built (python -m pvnet_amd.build).  The release library unless
+    a tuning knob is set in the environment (see TUNING_KNOBS; `reload_tuning()` re-decides after the environment changed)."""
     global _lib
     if _lib is not None:
         return _lib
-    lib_path = os.environ.get("PVNET_VOTE_LIB", LIB_PATH)  # development aid: an experimental build of the same ABI
+    _lib = _load(_wanted_library())
+    return _lib
+
+
+def _load(lib_path: str) -> C.CDLL:
+    if lib_path in _libs:
+        return _libs[lib_path]
     if not os.path.exists(lib_path):
         raise RuntimeError(f"pvnet_amd: HIP library {lib_path} is missing -- build it with "
                            f"`python -m pvnet_amd.build` (hipcc, gfx950). There is no CPU fallback.")
@@ -104,13 +125,16 @@ def load_library() -> C.CDLL:
     lib.pvnet_vote_tuning_reload.argtypes = []
     if lib.pvnet_vote_abi_version() != 9:
         raise RuntimeError("pvnet_amd: libpvnet_vote.so ABI version mismatch; rebuild it")
-    _lib = lib
+    _libs[lib_path] = lib
     return lib
 
 
 def reload_tuning():
-    """re-read the PVNET_* tuning environment variables (the library reads them once, at its first call)."""
-    load_library().pvnet_vote_tuning_reload()
+    """the PVNET_* tuning environment changed: pick the library again (release without knobs, the development build with) and have
+    the development build re-read them (it reads them once, at its first call; the release build's knobs are constants)."""
+    global _lib
+    _lib = _load(_wanted_library())
+    _lib.pvnet_vote_tuning_reload()
 
 
 def _check(rc: int, what: str):
@@ -197,7 +221,7 @@ def _debug_views(ws: torch.Tensor, L: Layout):
 
 def effective_literal(literal: bool, inlier_thresh: float) -> bool:
     """the scoring mode a call really runs in: the matrix-pipe modes fold tan(acos(thresh)) into their operands and need
-    1e-3 <= thresh < 1; outside that range the library scores literally (fill_params, pvnet_vote.hip)."""
+    1e-3 <= thresh < 1; outside that range the library scores literally (fill_params, vote_host.hip)."""
     t = float(inlier_thresh)
     t32 = struct.unpack('f', struct.pack('f', t))[0]  # the library compares the float32 it receives
     return bool(literal) or not (struct.unpack('f', struct.pack('f', 1e-3))[0] <= t32 < 1.0)
@@ -210,7 +234,18 @@ def mode_flags(literal: bool, approx: bool, inlier_thresh: float) -> int:
     ``approx``: matrix-pipe scoring without the re-evaluation (counts within a few votes of the reference's)."""
     if effective_literal(literal, inlier_thresh):
         return F_LITERAL
-    return F_APPROX if approx else 0
+    return F_APPROX if approx else _CULL_FLAG
+
+
+_CULL_FLAG = 0
+
+
+def set_cull_selection(which):
+    """Which key-points the exact mode disc-culls in the calls that follow: None (the default) -- the library selects per image on
+    the device; "all" / "none" -- PVNET_F_CULL_ALL / PVNET_F_CULL_NONE.  The inlier counts are the same integers under every
+    selection (tests/conftest.py runs the parity modules under two of them); only the time differs."""
+    global _CULL_FLAG
+    _CULL_FLAG = {None: 0, "all": F_CULL_ALL, "none": F_CULL_NONE}[which]
 
 
 _last_stream = {}  # device index -> the stream of the previous voting call on that device

@@ -38,10 +38,10 @@ def pytest_generate_tests(metafunc):
 def cull_selection(request, monkeypatch):
     from pvnet_amd import voting
     if getattr(request, "param", "library_selects") == "every_keypoint_culled":
-        monkeypatch.setenv("PVNET_SCORE_CULL", "1")
-        voting.reload_tuning()
-        yield "every_keypoint_culled"
-        monkeypatch.delenv("PVNET_SCORE_CULL", raising=False)
-        voting.reload_tuning()
+        voting.set_cull_selection("all")   # PVNET_F_CULL_ALL on every call: the RELEASE library under the other selection
+        try:
+            yield "every_keypoint_culled"
+        finally:
+            voting.set_cull_selection(None)
     else:
         yield "library_selects"

@@ -1,4 +1,4 @@
-"""GPU tests of the exact mode's DISC CULLING (rounds 5-6; pvnet_vote.hip: cull_block of hypothesis_kernel / score_exact_kernel_cull;
+"""GPU tests of the exact mode's DISC CULLING (rounds 5-6; k3_hypotheses.hip: cull_block of hypothesis_kernel; k4_score_cull.hip: score_exact_kernel_both -- formerly score_exact_kernel_cull;
 PVNET_SCORE_CULL=1 culls every key-point, the default lets K3 select them per (image, key-point) from the spread of the band-origin
 candidates): a culled key-point's hypotheses are sorted along a Hilbert curve, every tile of 32 is described by a disc,
 and a pixel whose margin at the disc's centre exceeds the disc's radius (+ the rounding band) votes for all 32 hypotheses of the
@@ -208,7 +208,7 @@ def test_the_library_selects_clean_key_points_and_leaves_noisy_ones_to_the_full_
 
 
 def hilbert_index(x, y, bits):
-    """numpy restatement of hilbert_index() (pvnet_vote.hip): position of integer cells (x, y) on the 2^bits x 2^bits Hilbert curve"""
+    """numpy restatement of hilbert_index() (k3_hypotheses.hip): position of integer cells (x, y) on the 2^bits x 2^bits Hilbert curve"""
     x, y = x.astype(np.uint32).copy(), y.astype(np.uint32).copy()
     d = np.zeros_like(x)
     s = np.uint32(1 << (bits - 1))

@@ -189,7 +189,7 @@ def test_vote_epilogue_keeps_mfma_hazard_distance(tmp_path):
     spec = importlib.util.spec_from_file_location("check_mfma_hazard", os.path.join(ROOT, "tools", "check_mfma_hazard.py"))
     chk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(chk)
-    assert chk.main([]) == 0  # compiles pvnet_vote.hip to assembly with the product's flags
+    assert chk.main([]) == 0  # compiles the library's translation units to assembly with the product's flags
     bad = tmp_path / "bad.s"
     bad.write_text("_Z17score_mfma_kernelILi9EEv:\n"
                    "\tv_mfma_f32_32x32x16_bf16 v[2:17], v[144:147], v[82:85], 0\n"

@@ -1,4 +1,4 @@
-"""Build-time check of every kernel's register accounting (pvnet_vote.hip, pvnet_nn.hip).
+"""Build-time check of every kernel's register accounting (the translation units of libpvnet_vote.so, release and development build).
 
 Rule: a kernel must not use the last VGPR granule of its allocation -- `.amdhsa_next_free_vgpr` has to exceed the highest
 VGPR an instruction names by at least 8 (PVNET_SPARE_VGPRS in the sources provides the slack).  Background: round 2's
@@ -34,10 +34,10 @@ EXPECTED_ALLOC = [(r"\d+hypothesis_kernelI", 48, 48), (r"score_exact_kernel_[12]
                   (r"score_exact_kernel_8_\d_\d_2_", 168, 24), (r"score_exact_kernel_both_\d_0", 128, 256), (r"score_exact_kernel_both_\d_1", 136, 256)]
 
 
-def compile_to_asm(src, out):
+def compile_to_asm(src, out, dev=False):
     sys.path.insert(0, ROOT)
     from pvnet_amd import build as B
-    flags = [f for f in B.flags() if f not in ("-shared", "-fPIC")]
+    flags = [f for f in B.flags() if f not in ("-shared", "-fPIC")] + (["-DPVNET_DEV"] if dev else [])
     subprocess.check_call([B.hipcc_path()] + flags + ["-S", "--cuda-device-only", "-Wno-unused-command-line-argument", src, "-o", out],
                           stderr=subprocess.DEVNULL)
 
@@ -60,7 +60,7 @@ def kernels(text):
 
 
 def short(name):
-    return re.sub(r"^_ZN\d+_GLOBAL__N_1\d+", "", name)[:56]
+    return re.sub(r"^_ZN(3pvd)?\d+_GLOBAL__N_1\d+", "", name)[:56]
 
 
 def main(argv):
@@ -71,14 +71,22 @@ def main(argv):
         sys.path.insert(0, ROOT)
         from pvnet_amd import build as B
         with tempfile.TemporaryDirectory() as d:
-            for k, src in enumerate(B.SRC):
-                out = os.path.join(d, f"k{k}.s")
-                compile_to_asm(src, out)
-                texts.append(open(out).read())
+            from concurrent.futures import ThreadPoolExecutor
+            jobs = [(src, dev, os.path.join(d, f"k{k}{'d' if dev else ''}.s")) for k, src in enumerate(B.SRC) for dev in (False, True)
+                    if "rccl" not in src]   # release and development (-DPVNET_DEV) instantiations of every translation unit
+            with ThreadPoolExecutor(max_workers=max(1, (os.cpu_count() or 4) - 1)) as ex:
+                list(ex.map(lambda j: compile_to_asm(j[0], j[2], j[1]), jobs))
+            for _, _, out in jobs:
+                t = open(out).read()
+                texts.append(t)
     bad = 0
     n = 0
+    done = set()
     for t in texts:
         for name, nfv, vmax, scratch in kernels(t):
+            if (name, nfv, vmax, scratch) in done:   # the same kernel in the release and the development build
+                continue
+            done.add((name, nfv, vmax, scratch))
             n += 1
             slack = nfv - (vmax + 1)
             alloc = (nfv + 7) // 8 * 8

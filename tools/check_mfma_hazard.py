@@ -1,11 +1,11 @@
-"""Build-time check of the matrix-pipe scoring kernels' hand-placed vote epilogues (pvnet_vote.hip: vote8, vote8x).
+"""Build-time check of the matrix-pipe scoring kernels' hand-placed vote epilogues (k4_score_mfma.hip: vote8; k4_exact_body.h: vote_subs / vote_slow_*).
 
 vote8 reads MFMA result VGPRs from inside an inline-asm block.  LLVM inserts the gfx950 "XDL write VGPR -> VALU read"
 wait states only for instructions IT schedules; what an INLINEASM block reads is invisible to its hazard recogniser,
 so the distance between every v_mfma and the first instruction that reads (or overwrites) one of its result registers
 is re-checked here on the generated assembly:
 
-    python tools/check_mfma_hazard.py            # compiles pvnet_vote.hip to assembly (hipcc -S) and checks it
+    python tools/check_mfma_hazard.py            # compiles the scoring translation units to assembly (hipcc -S) and checks them
     python tools/check_mfma_hazard.py file.s
 
 Rule (LLVM GCNHazardRecognizer, gfx950 XDL ops): an N-pass MFMA needs N + 3 wait states before a VALU instruction may
@@ -32,12 +32,23 @@ def required(op):
     return PASSES.get(op, 16) + 3
 
 
+MFMA_TU = ("k4_score_mfma.hip", "k4_score_exact.hip", "k4_score_cull.hip")   # the translation units with matrix-pipe scoring kernels
+
+
 def compile_to_asm(out):
+    """the translation units of MFMA_TU, release and development instantiations, to ONE assembly text"""
     sys.path.insert(0, ROOT)
     from pvnet_amd import build as B
     flags = [f for f in B.flags() if f not in ("-shared", "-fPIC")]
-    cmd = [B.hipcc_path()] + flags + ["-S", "--cuda-device-only", "-Wno-unused-command-line-argument", B.SRC[0], "-o", out]
-    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+    text = ""
+    for src in B.SRC:
+        if os.path.basename(src) not in MFMA_TU:
+            continue
+        for dev in ([], ["-DPVNET_DEV"]):
+            cmd = [B.hipcc_path()] + flags + dev + ["-S", "--cuda-device-only", "-Wno-unused-command-line-argument", src, "-o", out]
+            subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+            text += open(out).read() + "\n"
+    open(out, "w").write(text)
 
 
 def vregs(tok):

@@ -3,7 +3,7 @@ of outlier directions x the inlier threshold at the benchmark shape (batch 32, 4
 configuration, runs the exact mode with NO key-point culled and with EVERY key-point culled (PVNET_SCORE_CULL = 0 / 1) on one box:
 scoring stage and whole call (one stream, event-timed), the share of the full kernel's steps the fine pass still executes, and the
 statistic K3's selection uses -- q = S / (rho tan(theta0)), S = spread of the eight candidate intersections of the band-origin
-estimate (kp_preamble, pvnet_vote.hip), recomputed here from the records of the call.  The crossover in q is what
+estimate (kp_preamble, k3_hypotheses.hip), recomputed here from the records of the call.  The crossover in q is what
 PVNET_CULL_Q_MILLI is set from; the last column is what the library's own selection (the default) then does.
     python tools/cull_crossover.py [quick]       (MI355X)   -> profiles/r06_cull_crossover.txt"""
 import os

@@ -3,7 +3,7 @@ CPU simulation, numpy, float64 predicate; nothing here runs in the product.
 
 The scoring kernel spends 2 MFMAs + 40 vector operations on every block of 32 pixels x 32 hypotheses.  A block could be
 skipped with all counts still exact when the outcome of its 1 024 tests is known from geometry alone -- outside the rounding
-band of the reference's float32 test (band_constant(), pvnet_vote.hip).  Three questions, per threshold and field:
+band of the reference's float32 test (band_constant(), vote_host.hip).  Three questions, per threshold and field:
 
  (V) the review's formulation: each key-point's hypotheses sorted by distance R from the key-point estimate o (the exact
      mode's band origin), its pixels sorted by |alpha| = deviation of the pixel's direction from the direction to o; a block is
@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 from pvnet_amd import synth  # noqa: E402
 
 
-def kband(t):  # band_constant() of pvnet_vote.hip
+def kband(t):  # band_constant() of vote_host.hip
     u = 2.0 ** -24
     tau = np.sqrt(1 - t * t) / t
     t0 = np.arccos(t)

@@ -1,4 +1,4 @@
-"""Development aid (round 6): shader-clock stamps of the phases of a culled key-point's K3 block (cull_block, pvnet_vote.hip) --
+"""Development aid (round 6): shader-clock stamps of the phases of a culled key-point's K3 block (cull_block, k3_hypotheses.hip) --
 needs a library built with -DPVNET_K3_PROBE (PVNET_VOTE_LIB points at it); every key-point culled.
     hipcc <build.flags()> -DPVNET_K3_PROBE pvnet_amd/csrc/*.hip -o _ab/lib_k3probe.so ; python tools/experiments/k3_probe.py"""
 import os

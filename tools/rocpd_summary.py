@@ -22,7 +22,7 @@ def inst(name):
     name = re.sub(r"\s*\[clone[^\]]*\]\s*$", "", name)
     name = re.sub(r"\(.*\)$", "", name).strip()
     # round 4: the exact scoring kernel's instantiations are plain functions (one amdgpu_num_vgpr literal each,
-    # pvnet_vote.hip PV_DEF_SCORE_EXACT): score_exact_kernel_<MH>_<FOLD>_<TIMED>_<NACC>_<RUNS> -> the template spelling
+    # k4_score_exact.hip PV_DEF_SCORE_EXACT): score_exact_kernel_<MH>_<FOLD>_<TIMED>_<NACC>_<RUNS> -> the template spelling
     m = re.match(r"(score_exact_kernel)_(\d+)_(\d+)_(\d+)_(\d+)_(\d+)$", name)
     if m:
         b = lambda x: "true" if x != "0" else "false"

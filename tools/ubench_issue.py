@@ -122,7 +122,7 @@ def body_ops(tmpl, with_mfma):
     return lines
 
 
-# ---- the shipped exact epilogue on fixed registers (vote8x_open / vote8x_close of pvnet_vote.hip), two accumulator pairs:
+# ---- the shipped exact epilogue on fixed registers (vote8x_open / vote8x_close of k4_exact_body.h), two accumulator pairs:
 #   pair P: a = v[10+32P : 25+32P], b = v[26+32P : 41+32P];  A/B operands v[2:9];  cnt v74, flg v75, acc v76, dm v77, x0..x3 v78..81,
 #   w0 w1 v82 v83, the SAD constant v84  -> 88 VGPRs, 5 waves per SIMD
 def epi_open(pa, pb, o):
