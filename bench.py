@@ -899,7 +899,9 @@ def main(argv=None):
                                           "one accumulator pair -- never a result",
                        "parallelism": f"images sharded over {world} GPU(s); steps issued round-robin on {nstreams} "
                                       f"HIP stream(s) per GPU"},
-            "roofline": {"kernel": f"{SCORE_KERNEL}<{L.wg_g * L.hpl // 2}, ...>", "bound": "mfma",
+            "roofline": {"kernel": f"{SCORE_KERNEL}<{L.wg_g * L.hpl // 2}, ...>" + (" (score_exact_kernel_both_*: ONE launch for dense and disc-culled work "
+                                                                                        "items; on this field K3 culls nothing)" if L.cull else ""),
+                         "bound": "mfma",
                          "achieved": alg_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": alg_tflops / PEAK_BF16_TFLOPS,
                          "definition": "SURVEY.md 8d: achieved = algorithmic_flop_per_pair x pair_tests_per_launch / "

@@ -8,8 +8,8 @@ import sys
 
 
 def short(name):
-    name = re.sub(r"\(anonymous namespace\)::", "", name)
-    name = re.sub(r"\(VoteParams\)", "", name)
+    name = re.sub(r"(pvd::)?\(anonymous namespace\)::", "", name)
+    name = re.sub(r"\((pvd::)?VoteParams\)", "", name)
     return name[:90]
 
 
@@ -17,7 +17,7 @@ def inst(name):
     """the kernel's name WITH its template arguments ("score_exact_kernel<8, false, false>"): the json summaries are keyed
     by instantiation, so that the literal-mode instantiations a profiled run also launches are never mixed into the
     timed ones"""
-    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"(pvd::)?\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
     name = re.sub(r"\s*\[clone[^\]]*\]\s*$", "", name)
     name = re.sub(r"\(.*\)$", "", name).strip()
@@ -27,6 +27,12 @@ def inst(name):
     if m:
         b = lambda x: "true" if x != "0" else "false"
         name = f"{m.group(1)}<{m.group(2)}, {m.group(3)}, {b(m.group(4))}, {m.group(5)}, {b(m.group(6))}>"
+    # round 6: the merged dense + disc-culling launch, score_exact_kernel_both_<TIMED>_<RUNS> (k4_score_cull.hip): the dense body is
+    # score_exact_body<8, 1, TIMED, 1, RUNS>
+    m = re.match(r"score_exact_kernel_both_(\d+)_(\d+)$", name)
+    if m:
+        b = lambda x: "true" if x != "0" else "false"
+        name = f"score_exact_kernel<8, 1, {b(m.group(1))}, 1, {b(m.group(2))}, +culling body>"
     return name if re.match(r"\w+_kernel(<.*>)?$", name) else None
 
 
