@@ -193,6 +193,16 @@ def _strides(t, n):
     return (C.c_int64 * n)(*[int(s) for s in t.stride()])
 
 
+class _DebugViews(dict):
+    """the debug dict of a call; "cull" (did the library disc-cull any key-point?) is worked out on first access"""
+
+    def __missing__(self, key):
+        if key == "cull":
+            self[key] = bool(self["cull_bits"].any().item())
+            return self[key]
+        raise KeyError(key)
+
+
 def _debug_views(ws: torch.Tensor, L: Layout):
     """typed views into the workspace (see PvnetVoteLayout) for tests / visualisation."""
     def view(off, nbytes, dtype, shape):
@@ -203,7 +213,7 @@ def _debug_views(ws: torch.Tensor, L: Layout):
     if L.cull:  # disc culling: sorted position -> caller's hypothesis index, the hypotheses in sorted order (culled key-points only)
         cull = dict(perm=view(L.off_perm, 4 * b * vn * hp, torch.int32, (b, vn, hp)),
                     hyps=view(L.off_hyps, 8 * b * vn * hp, torch.float32, (b, vn, hp, 2)))
-    return dict(
+    return _DebugViews(
         **cull,
         layout=L, ctrl=ctrl, tn0=ctrl[:b, 0], tn=ctrl[:b, 1], nchunks=ctrl[:b, 4], total_items=ctrl[b, 0],
         bits=view(L.off_bits, 8 * b * L.words, torch.int64, (b, L.words)),
@@ -379,11 +389,10 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
         # what the library really ran: without the matrix-pipe buffers (PVNET_SCORE_MODE=0) the default mode is scored literally
         d["mode"] = "literal" if (literal or (not approx and not L.reserved_)) else ("approx" if approx else "exact")
         d["concurrent"] = bool(flags & F_CONCURRENT)
-        # disc culling is decided on the device per (image, key-point): d["cull_bits"] is what the library recorded (not
-        # re-derived from the layout); d["cull"] = any key-point culled.  Reading it synchronises -- debug only.
-        if d["mode"] == "exact" and L.cull:
-            d["cull"] = bool(d["cull_bits"].any().item())
-        else:
+        # disc culling is decided on the device per image: d["cull_bits"] is what the library recorded (not re-derived
+        # from the layout); d["cull"] = any key-point culled -- evaluated when it is READ (it synchronises: v5 and the py-level
+        # generate_hypothesis go through this dict on every call and lost 37 us to it, profiles/r06p_bench_configs.txt)
+        if not (d["mode"] == "exact" and L.cull):
             d["cull"] = False
             d["cull_bits"] = torch.zeros((b, vn), dtype=torch.int32, device=dev)
         if band_stats:  # (cells re-evaluated, literal tests made) of this call; synchronises
