@@ -617,9 +617,26 @@ def main(argv=None):
     # gathers its OWN votes -- a bucket is GS consecutive steps of ONE stream, sent from that stream: stream order is the only
     # dependency (no event, no communication stream, no wait across streams), and no ProcessGroup stream takes a hardware queue.
     rg = None
+    gather_fallback = None
     if dist is not None and a.gather == "rccl":
         from pvnet_amd import distributed as D
-        rg = D.RcclGather(dev)
+        try:   # the communicator and one trial collective; every rank must end up on the same path, so the ranks agree on the outcome
+            rg = D.RcclGather(dev)
+            t_in = torch.full((4,), float(rank), dtype=torch.float32, device=dev)
+            t_out = torch.empty((world * 4,), dtype=torch.float32, device=dev)
+            rg.all_gather(t_out, t_in)
+            torch.cuda.synchronize(dev)
+            if t_out.view(world, 4)[:, 0].tolist() != [float(r) for r in range(world)]:
+                raise RuntimeError("trial all-gather returned wrong ranks")
+        except Exception as e:  # noqa: BLE001 -- any failure of the library's binding: torch.distributed's collective instead
+            gather_fallback = f"{type(e).__name__}: {e}"
+            rg = None
+        ok = torch.tensor([1 if rg is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if rg is not None:
+                gather_fallback = "another rank's RCCL binding failed"
+            rg = None
     GS = max(1, a.gather_bucket) if a.gather_bucket > 0 else 3   # steps per collective of a stream (rccl mode)
     if rg is not None:
         staging_s = [[torch.empty((GS, BATCH, VN, 2), dtype=torch.float32, device=dev) for _ in range(NBLK)] for _ in range(nstreams)]
@@ -879,7 +896,10 @@ def main(argv=None):
                                      "VALU (5 calls on one stream)"},
             "per_rank_votings_per_s": per_rank, "gather_ms": gather_ms,
             "gather_bucket_steps": G if dist is not None else None,
-            "gather_stream": ("a voting stream (BENCH_GATHER_ON_VOTING_STREAM=1)" if GATHER_ON_VOTE else "its own stream") if dist is not None else None,
+            "gather_stream": (("the voting stream that filled the bucket (the library's ncclAllGather, pvnet_vote_allgather)" if rg is not None
+                               else "a voting stream (BENCH_GATHER_ON_VOTING_STREAM=1)" if GATHER_ON_VOTE else "its own stream")
+                              if dist is not None else None),
+            "gather_fallback": gather_fallback,
             "rccl_ranks_seen": len(seen) if seen else None,
             "rank_devices": [{"rank": r, "local_rank": l, "device": d} for r, l, d in seen] if seen else None,
             "dtype": "f32 decisions (bf16x3 MFMA products, f32 accumulate; pairs inside the f32 rounding band re-evaluated "
