@@ -61,6 +61,19 @@ def main(base, out_dir):
     for n, (i, _, _) in enumerate(st):
         build(out_dir, f"one_{n:02d}", with_nops(lines, {i}))
         build(out_dir, f"pre_{n:02d}", with_nops(lines, (), {i}))
+    # level 2 (round 6, second call): no single site carries the effect, block LBB0_25 as a whole does (6 / 200 against 193 / 200,
+    # profiles/r06a_flake_bisect.txt) -- contiguous RANGES of that block's sites (the rank -> bit search's select chains), and every
+    # site EXCEPT that block's
+    b25 = [n for n, (_, blk, _) in enumerate(st) if blk == ".LBB0_25"]
+    if b25:
+        lo, hi = b25[0], b25[-1]
+        build(out_dir, "allbut_LBB0_25", with_nops(lines, {i for n, (i, _, _) in enumerate(st) if n < lo or n > hi}))
+        cuts = [(lo, lo + 2), (lo + 3, hi - 3), (hi - 2, hi), (lo, lo + 7), (lo + 8, hi), (lo + 3, lo + 7), (lo + 8, hi - 3),
+                (lo + 3, lo + 5), (lo + 6, lo + 8), (lo + 9, lo + 11), (lo + 12, hi - 3)]
+        for a, c in cuts:
+            build(out_dir, f"rng_{a:02d}_{c:02d}", with_nops(lines, {st[n][0] for n in range(a, c + 1)}))
+        for par in (0, 1):   # every other site of the block
+            build(out_dir, f"alt{par}_LBB0_25", with_nops(lines, {st[n][0] for n in b25 if (n - lo) % 2 == par}))
     print(f"{len(st)} v_cndmask sites, {len(os.listdir(out_dir))} files in {out_dir}")
 
 
