@@ -5,6 +5,8 @@ and a pixel whose margin at the disc's centre exceeds the disc's radius (+ the r
 tile or for none -- only the other pixels are gathered into MFMA tiles.  The claim under test: EVERY inlier count, every winner
 and every key-point is the one the full exact kernel (and therefore literal mode, i.e. the reference's own arithmetic:
 ransac_voting_kernel.cu:88-126) returns -- `torch.equal`, no tolerance -- while the work really shrinks."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -65,6 +67,33 @@ def test_culled_counts_equal_literal_and_full_kernel_at_the_bench_shape(cull, th
     assert 0 < ex < total                                   # and part of the full kernel's steps was really not executed
     if thresh == 0.9:
         assert ex < 0.6 * total
+
+
+def test_selection_flags_on_the_release_library():
+    """PVNET_F_CULL_ALL / PVNET_F_CULL_NONE (voting.set_cull_selection) on the RELEASE library -- no environment knob: the marks K3 records
+    follow the flag, the library's own selection culls a clean field and leaves the noisy benchmark field alone, and every selection
+    gives the same integers"""
+    for k in voting.TUNING_KNOBS:
+        assert not os.environ.get(k)
+    voting.reload_tuning()
+    assert b"release build" in voting.load_library().pvnet_vote_build_info()
+    mn, vn_, _ = batch(8, 300, 480, 640, 40)                                    # noisy: sigma 0.05, 10 % outliers
+    mc, vc, _ = batch(8, 300, 480, 640, 40, noise=False, background="zeros")    # the ground-truth field
+    try:
+        res = {}
+        for sel in (None, "all", "none"):
+            voting.set_cull_selection(sel)
+            for name, (m, v) in (("noisy", (mn, vn_)), ("clean", (mc, vc))):
+                out, d = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=5, return_debug=True)
+                res[sel, name] = (out.clone(), d["counts"].clone(), d["win"].clone(), d["cull_bits"].clone())
+    finally:
+        voting.set_cull_selection(None)
+    for name in ("noisy", "clean"):
+        assert bool(res["all", name][3].all()) and not bool(res["none", name][3].any())
+        for sel in (None, "all"):
+            assert torch.equal(res[sel, name][1], res["none", name][1]) and torch.equal(res[sel, name][2], res["none", name][2])
+            assert torch.equal(res[sel, name][0], res["none", name][0])
+    assert bool(res[None, "clean"][3].all()) and not bool(res[None, "noisy"][3].any())   # what the spread test decides on these fields
 
 
 @pytest.mark.skipif(not refkernels.available("off"), reason="oracle/_ref (the reference's kernels compiled for gfx950) not built")
