@@ -274,8 +274,8 @@ def reset_concurrent_hint(dev=None):
 
 def concurrent_hint(dev, concurrent: Optional[bool]) -> int:
     """PVNET_F_CONCURRENT or 0 for a call on the current stream of ``dev``.  The flag never changes a result; it picks the
-    variant of the scoring kernel that leaves registers to the small stages of OTHER batches in flight (+4 % throughput with
-    six batches on six streams, -5 % for a batch alone: include/pvnet_vote.h, profiles/r04_ab_runs.txt).  ``concurrent=None`` (the default of the callers): set when this
+    variant of the scoring kernel that leaves registers to the small stages of OTHER batches in flight (+3 % throughput with
+    six batches on six streams, re-measured in round 5: profiles/r05_ab_runs.txt; -5 % for a batch alone: profiles/r04_ab_runs.txt).  ``concurrent=None`` (the default of the callers): set when this
     call's stream differs from the stream of the previous call on the device -- a caller that alternates streams keeps
     batches in flight; one that stays on a stream (the reference's call sites, DataParallel replicas: one stream per device)
     does not."""
