@@ -73,8 +73,8 @@ def test_selection_flags_on_the_release_library():
     """PVNET_F_CULL_ALL / PVNET_F_CULL_NONE (voting.set_cull_selection) on the RELEASE library -- no environment knob: the marks K3 records
     follow the flag, the library's own selection culls a clean field and leaves the noisy benchmark field alone, and every selection
     gives the same integers"""
-    for k in voting.TUNING_KNOBS:
-        assert not os.environ.get(k)
+    if any(os.environ.get(k) for k in voting.TUNING_KNOBS):
+        pytest.skip("a PVNET_* knob is set in the environment: the front end loads the development build")
     voting.reload_tuning()
     assert b"release build" in voting.load_library().pvnet_vote_build_info()
     mn, vn_, _ = batch(8, 300, 480, 640, 40)                                    # noisy: sigma 0.05, 10 % outliers
