@@ -87,14 +87,18 @@ __device__ __forceinline__ uint32_t hilbert_index(uint32_t x, uint32_t y, int bi
 //   origin   eight candidate intersections from FIXED pixel pairs spread over the foreground list (records t and t + tn / 2), their
 //            component-wise median, rounded to integers.  It only scales the band -- no result depends on it -- so a bad estimate
 //            (fewer than three usable candidates: the image's median pixel instead) costs re-evaluations, never correctness.
-//   culling  P.cull = 1: every key-point (PVNET_SCORE_CULL=1: tests and probes); P.cull = 2 (the default where the layout supports
-//            it): a key-point VOTES for culling when its candidates lie close together -- spread S (median Chebyshev distance
-//            from the median point) <= cull_q rho tan(theta0), i.e. the field's angular noise is small against the threshold
-//            angle, so most pixels are certain for most hypothesis tiles and the gathered rest is cheaper than the dense sweep
-//            (crossover measured: profiles/r06_cull_crossover.txt) -- and the IMAGE's key-points are culled together when the
-//            majority votes so (image_culled()): the spread of eight candidates scatters, and a call whose key-points split between
-//            the two scoring kernels pays the fixed cost of both (r06d: 220 us against 197 none / 174 all culled at sigma 0.01).
+//   culling  P.cull = 1: every key-point (PVNET_F_CULL_ALL; PVNET_SCORE_CULL=1: tests and probes); P.cull = 2 (the default where the
+//            layout supports it): a key-point VOTES for culling when ALL BUT ONE of its candidates lie close together -- the seventh
+//            smallest of the eight Chebyshev distances from the median point <= cull_q rho tan(theta0): the field's angular noise is
+//            small against the threshold angle AND few directions are outliers (a candidate is off when either pixel of its pair
+//            is: with 20 % outliers two or three of eight are, the hypothesis cloud is wide, and the gathered rest costs more than
+//            the dense sweep although the MEDIAN distance -- the first form of this test -- is still zero:
+//            profiles/r06x_cull_crossover_outliers.txt); then most pixels are certain for most hypothesis tiles (crossover
+//            measured: profiles/r06y_cull_crossover.txt).  The IMAGE's key-points are culled together when the majority votes so
+//            (image_culled()): eight candidates scatter, and one selection per image keeps its items of one kind.
 //            Any choice gives the same counts; a wrong one only costs time.
+//            (Round 6 also tried the candidates' medians and ranks through lane shuffles instead of LDS + barriers: ds_bpermute made
+//            the preamble 5 k cycles longer, quad permutes + ds_swizzle 2 k -- r07a, r07b; the LDS form stays.)
 struct KpShared {
     float cand[KP_MAX * NCAND * 2];
     float med[KP_MAX * 2];
@@ -162,8 +166,9 @@ __device__ __forceinline__ void kp_preamble(const VoteParams& P, int bi, int tn,
             const bool kp = (dj + rho) * (1.f + (dist + ro) / rho) < (dist + dj + rho) * (1.f + ro / rho);
             S.org[kk * 2] = kp ? (int)rintf(mx) : pm % P.w;
             S.org[kk * 2 + 1] = kp ? (int)rintf(my) : pm / P.w;
-            S.vote[kk] = P.cull == 1 || (P.cull == 2 && kp && dj <= P.cull_q * rho * P.tau) ? 1 : 0;
         }
+        if (dj == dj && rank == (n / 2 > n - 2 ? n / 2 : n - 2))   // the largest distance but one (n <= 4: the median one)
+            S.vote[kk] = P.cull == 1 || (P.cull == 2 && dj <= P.cull_q * band_rho(tn) * P.tau) ? 1 : 0;
     } else if (mine && j == 0) {   // fewer than three usable candidates
         S.org[kk * 2] = pm % P.w;
         S.org[kk * 2 + 1] = pm / P.w;

@@ -31,8 +31,8 @@ constexpr int SEG_WORDS = 64;          // a segment = 64 words = 4096 pixels: th
 #define PVNET_SMALL_PRIO 3
 #endif
 #ifndef PVNET_CULL_Q_MILLI
-#define PVNET_CULL_Q_MILLI 500 // a key-point votes for disc culling when its candidate intersections spread over <= 0.5 rho tan(theta0)
-                               // (profiles/r06k_cull_crossover.txt: culling wins up to a median q of 0.5 - 0.65)
+#define PVNET_CULL_Q_MILLI 1000 // a key-point votes for disc culling when all but one of its eight candidate intersections lie within
+                                // 1.0 rho tan(theta0) of their median point (k3_hypotheses.hip kp_preamble; profiles/r06y_cull_crossover.txt)
 #endif
 #ifndef PVNET_CULL_DEFAULT
 #define PVNET_CULL_DEFAULT 2   // what PVNET_SCORE_CULL = -1 (not set) means: 0 = never, 1 = every key-point, 2 = the key-points K3 selects
@@ -525,7 +525,7 @@ struct Tuning {
                         //                         pixels gathered: score_exact_kernel_cull) of 2 = the key-points K3 selects from the
                         //                         spread of their candidate intersections (the default: PVNET_CULL_DEFAULT), 1 = every
                         //                         key-point (tests, probes), 0 = none (the layout then has no culling buffers)
-    int cull_q_milli;   // PVNET_CULL_Q_MILLI      the selection threshold of 2, in thousandths (kp_preamble; profiles/r06_cull_crossover.txt)
+    int cull_q_milli;   // PVNET_CULL_Q_MILLI      the selection threshold of 2, in thousandths (kp_preamble; profiles/r06y_cull_crossover.txt)
     int exact_fold;     // PVNET_EXACT_FOLD        exact mode: -1 (default) = by threshold, 0 = one cell per work item and
                         //                         hypothesis, 1 = one cell per pixel tile (band_fold1())
     int dev_stages;     // PVNET_DEV_STAGES        development aid: bit mask of the stages to launch

@@ -1,6 +1,6 @@
 """Development aid (round 6): shader-clock stamps of the phases of a culled key-point's K3 block (cull_block, k3_hypotheses.hip) --
-needs a library built with -DPVNET_K3_PROBE (PVNET_VOTE_LIB points at it); every key-point culled.
-    hipcc <build.flags()> -DPVNET_K3_PROBE pvnet_amd/csrc/*.hip -o _ab/lib_k3probe.so ; python tools/experiments/k3_probe.py"""
+needs a library built with -DPVNET_K3_PROBE (PVNET_VOTE_LIB points at it); every key-point culled (PVNET_F_CULL_ALL).
+    python tools/experiments/variant_lib.py _ab/lib_k3probe.so k3_hypotheses.hip:-DPVNET_K3_PROBE ; python tools/experiments/k3_probe.py"""
 import os
 import sys
 
@@ -9,8 +9,9 @@ import torch
 
 sys.path.insert(0, os.getcwd())
 os.environ.setdefault("PVNET_VOTE_LIB", os.path.abspath("_ab/lib_k3probe.so"))
-os.environ["PVNET_SCORE_CULL"] = "1"
 from pvnet_amd import synth, voting  # noqa: E402
+
+voting.set_cull_selection("all")
 
 dev = torch.device("cuda:0")
 mask, planar, _ = synth.make_batch(32, radius=40, noise=True, background="normal")
