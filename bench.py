@@ -473,14 +473,15 @@ def secondary_block(sets, rank, dev, budget_s=3.0):
             plan(m, v, seed=SEED0 + i)
         torch.cuda.synchronize(dev)
         dt = (time.perf_counter() - t0) / steps
-        _, dbg, st = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, max_num=max_num, seed=SEED0,
+        # (on the plan's workspace: whether a batch may be disc-culled follows the previous call on the SAME workspace, vote_common.h)
+        _, dbg, st = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, max_num=max_num, seed=SEED0, workspace=plan.workspace,
                                                    image_offset=rank * BATCH, return_debug=True, stage_times=True, concurrent=False)
         counts, win = dbg["counts"].clone(), dbg["win"].clone()
         tn = float(dbg["tn"].float().mean())
         # (the statistics come from a call of their own: every wave adds its step counts to ONE word, 24 k same-address atomics that
         #  took the scoring stage of the clean field from 55 to 419 us when they shared the event-timed call -- r06n)
         _, dbg = voting.ransac_voting_layer_v3(m, v, hn, inlier_thresh=thresh, max_num=max_num, seed=SEED0, image_offset=rank * BATCH,
-                                               return_debug=True, concurrent=False, band_stats=True)
+                                               return_debug=True, concurrent=False, band_stats=True, workspace=plan.workspace)
         # disc culling (the library selects it per image on the device): the share of (image, key-point)s it culled, and the pair tests
         # the launch really EXECUTED -- all of the dense key-points', of the culled ones the fine pass's share (steps executed / steps
         # of the dense kernel) plus the coarse pass (every pixel against the 32 tile centres of a slice)

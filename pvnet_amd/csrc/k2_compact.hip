@@ -161,7 +161,13 @@ __global__ __launch_bounds__(256) void compact_kernel(VoteParams P) {
                 P.ctrl[bi * CTRL_STRIDE + C_TN0] = tn0;
                 P.ctrl[bi * CTRL_STRIDE + C_TN] = tn;
                 P.ctrl[bi * CTRL_STRIDE + C_STATUS] = total > usable ? PVNET_S_OVERFLOW : 0;
-                if (bi == 0) call_flags_ptr(P)[CF_ANY_CULLED] = 0;   // (K3 sets it)
+                if (bi == 0) {   // the call's flags (vote_common.h): K3 sets / adds to them
+                    int32_t* cf = call_flags_ptr(P);
+                    const bool prev = P.ctrl[P.b * CTRL_STRIDE + 6] == P.layout_fp;   // a previous call of this layout left its votes here
+                    cf[CF_BATCH_OK] = (!prev || 3 * cf[CF_VOTES_NOW] >= 2 * P.b) ? 1 : 0;
+                    cf[CF_VOTES_NOW] = 0;
+                    cf[CF_ANY_CULLED] = 0;
+                }
             }
         }
         const int tpad = (tn + PAD - 1) / PAD * PAD;  // sentinel records: zero direction never votes

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(20))) void hypo
             int32_t* o = band_origin_ptr(P, bk);
             o[0] = S.org[threadIdx.x * 2];
             o[1] = S.org[threadIdx.x * 2 + 1];
-            *kp_cull_ptr(P, bk) = (P.cull && image_culled(S, P.vn)) ? 1 : 0;
+            *kp_cull_ptr(P, bk) = (P.cull && live && image_culled(S, P.vn) && (P.cull == 1 || call_flags_ptr(P)[CF_BATCH_OK])) ? 1 : 0;
         }
     } else if (!LITERAL && P.mode && P.exact && blk == 0) {   // more than KP_MAX key-points: the image's median pixel for all of them
         int pm = 0;
@@ -463,8 +463,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(20))) void hypo
         }
     }
     // (fill_params: P.cull implies the exact mode and vn <= KP_MAX) this image's key-points go to the disc-culling kernel
-    const bool culling = !LITERAL && P.cull && kp_origin && live && image_culled(S, P.vn);
+    // -- when the image's key-points vote for it AND the previous batch's majority did (CF_BATCH_OK, vote_common.h)
+    const bool votes = !LITERAL && P.cull && kp_origin && live && image_culled(S, P.vn);
+    const bool culling = votes && (P.cull == 1 || call_flags_ptr(P)[CF_BATCH_OK] != 0);
     if (blk == nbd) {      // one extra block per image plans its scoring work items (consumed by the next launches only)
+        if (votes && P.cull == 2 && threadIdx.x == 0) atomicAdd(call_flags_ptr(P) + CF_VOTES_NOW, 1);
         plan_image(P, bi, culling);
         return;
     }

@@ -123,6 +123,14 @@ struct VoteParams {
 // image 0's last segment), set by K3's plan blocks, read by the merged scoring launch, whose workgroups enter the culling body only then
 // (a call without culled key-points pays one scalar load for the merged launch)
 constexpr int CF_ANY_CULLED = 0;
+// CF_VOTES_NOW: images of this call whose key-points voted for disc culling (K3's plan blocks add theirs); CF_BATCH_OK: may this call's
+// images be culled at all?  K2 (the same thread that zeroes CF_ANY_CULLED) decides it from the PREVIOUS call on this workspace: yes when
+// at least two thirds of that call's images voted for culling, or when the workspace holds no previous call of this layout (the
+// fingerprint in ctrl's global row).  A culled image makes the hypothesis launch 9 us longer for the whole batch (its key-points' sort
+// blocks are the launch's longest chain), which ONE culled image of 32 never earns back (profiles/r06y_cull_crossover.txt: 3 % culled,
+// 193.7 us against 176): callers that vote batch after batch of one kind of field -- a network's output -- get the selection of the
+// previous batch's majority, from the second call on.  Like every selection it changes the time only, never a count.
+constexpr int CF_VOTES_NOW = 1, CF_BATCH_OK = 2;
 __device__ __forceinline__ int32_t* call_flags_ptr(const VoteParams& P) {
     return P.ctrl + (size_t)(P.b + 1) * CTRL_STRIDE + 3 * (size_t)P.b * P.vn;
 }

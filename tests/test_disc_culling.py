@@ -79,12 +79,14 @@ def test_selection_flags_on_the_release_library():
     assert b"release build" in voting.load_library().pvnet_vote_build_info()
     mn, vn_, _ = batch(8, 300, 480, 640, 40)                                    # noisy: sigma 0.05, 10 % outliers
     mc, vc, _ = batch(8, 300, 480, 640, 40, noise=False, background="zeros")    # the ground-truth field
+    L = voting.vote_layout(8, 480, 640, 9, 1024, 30000)
     try:
         res = {}
         for sel in (None, "all", "none"):
             voting.set_cull_selection(sel)
             for name, (m, v) in (("noisy", (mn, vn_)), ("clean", (mc, vc))):
-                out, d = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=5, return_debug=True)
+                ws = torch.zeros(L.total_bytes, dtype=torch.uint8, device=dev())   # no previous call on this workspace
+                out, d = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=5, return_debug=True, workspace=ws)
                 res[sel, name] = (out.clone(), d["counts"].clone(), d["win"].clone(), d["cull_bits"].clone())
     finally:
         voting.set_cull_selection(None)
@@ -94,6 +96,37 @@ def test_selection_flags_on_the_release_library():
             assert torch.equal(res[sel, name][1], res["none", name][1]) and torch.equal(res[sel, name][2], res["none", name][2])
             assert torch.equal(res[sel, name][0], res["none", name][0])
     assert bool(res[None, "clean"][3].all()) and not bool(res[None, "noisy"][3].any())   # what the spread test decides on these fields
+
+
+def test_a_batch_follows_the_previous_batch_on_its_workspace():
+    """whether a call's images may be disc-culled at all is decided from the PREVIOUS call on the same workspace (CF_BATCH_OK,
+    vote_common.h): two thirds of its images must have voted for culling.  A batch of 2 clean + 6 noisy images: the first call on a fresh
+    workspace culls the two clean ones, the second none; a clean batch keeps being culled; a clean batch behind a noisy one is scored
+    densely once, then culled.  The key-points, counts and winners never change."""
+    if any(os.environ.get(k) for k in voting.TUNING_KNOBS):
+        pytest.skip("a PVNET_* knob is set in the environment")
+    voting.reload_tuning()
+    mn, vn_, _ = batch(8, 300, 480, 640, 40)
+    mc, vc, _ = batch(8, 300, 480, 640, 40, noise=False, background="zeros")
+    mm = torch.cat([mc[:2], mn[2:]])
+    vm = torch.cat([vc[:2].contiguous(), vn_[2:].contiguous()])   # (a contiguous field here: strides are the caller's business)
+    L = voting.vote_layout(8, 480, 640, 9, 1024, 30000)
+    ws = torch.zeros(L.total_bytes, dtype=torch.uint8, device=dev())
+
+    def call(m, v):
+        out, d = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=0.99, seed=9, return_debug=True, workspace=ws)
+        return out.clone(), d["counts"].clone(), d["win"].clone(), d["cull_bits"].clone()
+    a1, a2 = call(mm, vm), call(mm, vm)
+    assert a1[3][:2].all() and not a1[3][2:].any()          # fresh workspace: every image that votes for it is culled
+    assert not a2[3].any()                                   # 2 of 8 voted: the next batch is scored densely
+    for x, y in zip(a1[:3], a2[:3]):
+        assert torch.equal(x, y)
+    c1, c2, c3 = call(mc, vc), call(mc, vc), call(mc, vc)    # behind a batch that did not vote for culling: dense once, then culled
+    assert not c1[3].any() and c2[3].all() and c3[3].all()
+    for x, y in zip(c1[:3], c3[:3]):
+        assert torch.equal(x, y)
+    n1 = call(mn, vn_)
+    assert not n1[3].any()
 
 
 @pytest.mark.skipif(not refkernels.available("off"), reason="oracle/_ref (the reference's kernels compiled for gfx950) not built")
@@ -209,8 +242,11 @@ def test_the_library_selects_clean_key_points_and_leaves_noisy_ones_to_the_full_
     culled, the noisy benchmark field's are not, and a batch that holds both gets both kernels in one call; every count equals
     literal mode's either way"""
     cull("auto")
+
+    def fresh():   # a workspace without a previous call: whether a batch may be culled at all follows the previous call on its workspace
+        return torch.zeros(voting.vote_layout(32, 480, 640, 9, 1024, 30000).total_bytes, dtype=torch.uint8, device=dev())
     mc, vc, _ = batch(32, 300, 480, 640, 40, noise=False, background="zeros")
-    _, d = voting.ransac_voting_layer_v3(mc, vc, 1024, inlier_thresh=0.99, seed=1, return_debug=True, band_stats=True)
+    _, d = voting.ransac_voting_layer_v3(mc, vc, 1024, inlier_thresh=0.99, seed=1, return_debug=True, band_stats=True, workspace=fresh())
     assert d["layout"].cull == 1 and bool(d["cull_bits"].all())
     ex, total = d["cull_stats"]
     assert total > 0 and ex < 0.05 * total
@@ -218,12 +254,12 @@ def test_the_library_selects_clean_key_points_and_leaves_noisy_ones_to_the_full_
     _, dl = voting.ransac_voting_layer_v3(mc, vc, 1024, inlier_thresh=0.99, seed=1, literal=True, return_debug=True)
     assert torch.equal(cc, dl["counts"])
     mn, vn_, _ = batch(32, 300, 480, 640, 40)
-    _, d = voting.ransac_voting_layer_v3(mn, vn_, 1024, inlier_thresh=0.99, seed=1, return_debug=True, band_stats=True)
+    _, d = voting.ransac_voting_layer_v3(mn, vn_, 1024, inlier_thresh=0.99, seed=1, return_debug=True, band_stats=True, workspace=fresh())
     assert d["layout"].cull == 1 and float(d["cull_bits"].float().mean()) < 0.1   # (a lucky draw of candidates may cull a key-point)
     # a mixed batch: even images clean, odd images noisy
     mm, vm = mn.clone(), vn_.clone()
     mm[0::2], vm[0::2] = mc[0::2], vc[0::2]
-    out, d = voting.ransac_voting_layer_v3(mm, vm, 1024, inlier_thresh=0.99, seed=1, return_debug=True, band_stats=True)
+    out, d = voting.ransac_voting_layer_v3(mm, vm, 1024, inlier_thresh=0.99, seed=1, return_debug=True, band_stats=True, workspace=fresh())
     bits = d["cull_bits"].clone()
     assert bool(bits[0::2].all()) and float(bits[1::2].float().mean()) < 0.1
     cm, wm = d["counts"].clone(), d["win"].clone()
