@@ -81,6 +81,9 @@ def measure(m, v, thresh, reps):
         voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=thresh, seed=i, workspace=ws)
     torch.cuda.synchronize()
     res["call_us"] = (time.perf_counter() - t0) / reps * 1e6
+    # what the library culls in the STEADY state: whether a batch may be culled follows the previous call on its workspace (vote_common.h)
+    _, dbg2 = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=thresh, seed=7, workspace=ws, return_debug=True)
+    res["bits"] = float(dbg2["cull_bits"].float().mean())
     st = []
     for i in range(5):
         _, t = voting.ransac_voting_layer_v3(m, v, 1024, inlier_thresh=thresh, seed=i, workspace=ws, stage_times=True)
