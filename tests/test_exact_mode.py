@@ -20,9 +20,9 @@ def dev():
     return torch.device("cuda:0")
 
 
-def batch(n, first, h, w, radius, noise=True, background="normal"):
+def batch(n, first, h, w, radius, noise=True, background="normal", **kw):
     mask, planar, kpts = synth.make_batch(n, first_index=first, h=h, w=w, radius=radius, noise=noise,
-                                          background=background)
+                                          background=background, **kw)
     m = torch.from_numpy(mask).to(dev())
     v = synth.planar_to_vertex_view(torch.from_numpy(planar).to(dev()))
     return m, v, kpts
@@ -323,3 +323,17 @@ def test_more_than_32_keypoints_use_the_image_origin():
     assert torch.equal(de["counts"], cl)
     org = de["band_origin"][0].cpu().numpy()
     assert (org == org[0]).all()   # one origin for all 40
+
+
+@pytest.mark.parametrize("vn", [32, 33, 40])
+def test_many_key_points(vn):
+    """the band origin (and the culling selection) is estimated per key-point for up to 32 of them -- eight candidate lanes each, all 256
+    threads of a K3 block at vn = 32; beyond that every key-point takes the image's median pixel as origin and nothing is culled.
+    Either way: the reference's integers."""
+    m, v, _ = batch(3, 910, 120, 160, 15, vn=vn)
+    _, lit, _, ex = both_modes(m, v, 256, 0.99)
+    assert_same_integers(lit, ex, 3)
+    mc, vc, _ = batch(3, 910, 120, 160, 15, vn=vn, noise=False, background="zeros")
+    ol, lit, oe, ex = both_modes(mc, vc, 256, 0.99)
+    assert_same_integers(lit, ex, 3)
+    assert float((ol - oe).abs().max()) < 1e-3
