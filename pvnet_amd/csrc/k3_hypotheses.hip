@@ -192,21 +192,6 @@ __device__ __forceinline__ void kp_preamble(const VoteParams& P, int bi, int tn,
 // Padding hypotheses (>= hn) sort to the end; a tile without a real hypothesis is never scored.
 // Round 6: 256 threads with four keys each (round 5: 1 024 threads, one key each, 40 us for 288 blocks -- two rounds on 256 CUs and
 // sixteen waves per barrier); a block of four waves is resident wherever a hypothesis block is.
-// v of lane (l ^ M), M a power of two below 64, without the LDS crossbar's address operand: DPP for 1, 2 and 8 (quad_perm, row_ror:8),
-// gfx950's row / half-wave swaps for 16 and 32, ds_swizzle's bit mode for 4
-__device__ __forceinline__ uint32_t lane_xor(uint32_t v, int m) {
-    if (m == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1, 0, 3, 2]
-    if (m == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2, 3, 0, 1]
-    if (m == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);               // and 0x1F, or 0, xor 4
-    if (m == 8) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);   // row_ror:8
-    const int lane = (int)(threadIdx.x & 63);
-    if (m == 16) {   // rows of 16 lanes: r[0] = (R0, R0, R2, R2), r[1] = (R1, R1, R3, R3)
-        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-        return (lane & 16) ? r[0] : r[1];
-    }
-    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // r[0] = (lo, lo), r[1] = (hi, hi)
-    return (lane & 32) ? r[0] : r[1];
-}
 
 // (-DPVNET_K3_PROBE, tools/experiments/k3_probe.py: shader-clock stamps of the block's phases into the unused tail of the item list)
 #ifdef PVNET_K3_PROBE
@@ -430,6 +415,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(20))) void hypo
     const long long k3_t0 = 0;
 #endif
     const int tn = P.ctrl[bi * CTRL_STRIDE + C_TN];
+    // (requested with the image's counts, long before it is needed: behind the preamble it was a dependent load of its own, 4 us of a
+    //  culled call's hypothesis launch -- r07k)
+    const bool batch_ok = P.cull == 1 || (P.cull == 2 && call_flags_ptr(P)[CF_BATCH_OK] != 0);
     const bool live = P.ctrl[bi * CTRL_STRIDE + C_TN0] >= P.min_num && tn > 0;  // gates of :531-534
     __shared__ KpShared S;
     const bool kp_origin = !LITERAL && P.mode && P.exact && P.vn <= KP_MAX;   // block-uniform
@@ -450,7 +438,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(20))) void hypo
             int32_t* o = band_origin_ptr(P, bk);
             o[0] = S.org[threadIdx.x * 2];
             o[1] = S.org[threadIdx.x * 2 + 1];
-            *kp_cull_ptr(P, bk) = (P.cull && live && image_culled(S, P.vn) && (P.cull == 1 || call_flags_ptr(P)[CF_BATCH_OK])) ? 1 : 0;
+            *kp_cull_ptr(P, bk) = (P.cull && live && batch_ok && image_culled(S, P.vn)) ? 1 : 0;
         }
     } else if (!LITERAL && P.mode && P.exact && blk == 0) {   // more than KP_MAX key-points: the image's median pixel for all of them
         int pm = 0;
@@ -465,7 +453,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(20))) void hypo
     // (fill_params: P.cull implies the exact mode and vn <= KP_MAX) this image's key-points go to the disc-culling kernel
     // -- when the image's key-points vote for it AND the previous batch's majority did (CF_BATCH_OK, vote_common.h)
     const bool votes = !LITERAL && P.cull && kp_origin && live && image_culled(S, P.vn);
-    const bool culling = votes && (P.cull == 1 || call_flags_ptr(P)[CF_BATCH_OK] != 0);
+    const bool culling = votes && batch_ok;
     if (blk == nbd) {      // one extra block per image plans its scoring work items (consumed by the next launches only)
         if (votes && P.cull == 2 && threadIdx.x == 0) atomicAdd(call_flags_ptr(P) + CF_VOTES_NOW, 1);
         plan_image(P, bi, culling);

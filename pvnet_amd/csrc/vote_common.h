@@ -388,20 +388,44 @@ __device__ __forceinline__ void a_rows_exact(float4 q, float tau, float ox, floa
     a_row(My, -Mx, -Ec, blo, bhi);                              // cr' rows
 }
 
+// v of lane (l ^ M), M a power of two below 64, without the LDS crossbar's address operand: DPP for 1, 2 and 8 (quad_perm, row_ror:8),
+// gfx950's row / half-wave swaps for 16 and 32, ds_swizzle's bit mode for 4
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v, int m) {
+    if (m == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1, 0, 3, 2]
+    if (m == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2, 3, 0, 1]
+    if (m == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);               // and 0x1F, or 0, xor 4
+    if (m == 8) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);   // row_ror:8
+    const int lane = (int)(threadIdx.x & 63);
+    if (m == 16) {   // rows of 16 lanes: r[0] = (R0, R0, R2, R2), r[1] = (R1, R1, R3, R3)
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane & 16) ? r[0] : r[1];
+    }
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // r[0] = (lo, lo), r[1] = (hi, hi)
+    return (lane & 32) ? r[0] : r[1];
+}
+
+// Wave reductions as a butterfly over lane ^ 1, 2, 4, 8, 16, 32: EVERY lane ends with the result, and no step goes through the LDS
+// crossbar with an address operand (round 6: the __shfl_down forms -- 6 ds_bpermute per 32-bit word, each a dependent LDS round trip
+// of ~100-200 cycles -- cost select_refine_kernel's five float64 sums and its 64-bit arg-max key 72 of them on its critical path).
+// (float64 sums come out in a different order than a sequential loop's: the refinement's tolerance is 1e-3 px, its sums agree to 1e-15)
 __device__ __forceinline__ int wave_reduce_add(int v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    for (int m = 1; m < 64; m <<= 1) v += (int)lane_xor((uint32_t)v, m);
     return v;
 }
 __device__ __forceinline__ double wave_reduce_add(double v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    for (int m = 1; m < 64; m <<= 1) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const unsigned long long o = (unsigned long long)lane_xor((uint32_t)b, m) | ((unsigned long long)lane_xor((uint32_t)(b >> 32), m) << 32);
+        v += __longlong_as_double((long long)o);
+    }
     return v;
 }
 __device__ __forceinline__ unsigned long long wave_reduce_max(unsigned long long v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        unsigned long long t = __shfl_down(v, o, 64);
+    for (int m = 1; m < 64; m <<= 1) {
+        const unsigned long long t = (unsigned long long)lane_xor((uint32_t)v, m) | ((unsigned long long)lane_xor((uint32_t)(v >> 32), m) << 32);
         v = t > v ? t : v;
     }
     return v;
