@@ -2,7 +2,7 @@
 
     python tools/overlap_summary.py <trace_results.db> [out.txt] [csv] [focus]
 
-`focus` (default "score_exact_kernel_8_1_0_1_1", the contiguous-runs scoring kernel that only calls flagged PVNET_F_CONCURRENT run):
+`focus` (default "score_exact_kernel_both_0_1": the merged dense + disc-culling launch with contiguous runs in its dense body, the scoring kernel that only calls flagged PVNET_F_CONCURRENT run):
 the window is the middle 80 % of the longest stretch of dispatches of THAT kernel no other scoring kernel interrupts -- bench.py's
 six-stream regions -- so the
 single-stream and approximate-mode regions of the same run stay out of the numbers.
@@ -19,7 +19,7 @@ import sys
 
 
 def short(n):
-    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"(pvd::)?\(anonymous namespace\)::", "", n)
     n = re.sub(r"^void ", "", n)
     n = re.sub(r"\(.*$", "", n)
     return n.strip()
@@ -56,7 +56,7 @@ def level_shares(iv, w0, w1):
     return out
 
 
-def main(db, out=None, csv=None, focus="score_exact_kernel_8_1_0_1_1", f0=0.1, f1=0.9):
+def main(db, out=None, csv=None, focus="score_exact_kernel_both_0_1", f0=0.1, f1=0.9):
     cur = sqlite3.connect(db).cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     grp = next((c for c in ("stream_id", "stream", "queue_id", "queue") if c in cols), None)
