@@ -1,6 +1,6 @@
-"""GPU tests of the exact mode's DISC CULLING (rounds 5-6; k3_hypotheses.hip: cull_block of hypothesis_kernel; k4_score_cull.hip: score_exact_kernel_both -- formerly score_exact_kernel_cull;
-PVNET_SCORE_CULL=1 culls every key-point, the default lets K3 select them per (image, key-point) from the spread of the band-origin
-candidates): a culled key-point's hypotheses are sorted along a Hilbert curve, every tile of 32 is described by a disc,
+"""GPU tests of the exact mode's DISC CULLING (rounds 5-6; k3_hypotheses.hip: cull_block of hypothesis_kernel; k4_score_cull.hip:
+score_exact_kernel_both.  PVNET_F_CULL_ALL / PVNET_SCORE_CULL=1 (development build) cull every key-point; by default K3 selects per
+image from the spread of the band-origin candidates, gated per batch by the previous call on the workspace): a culled key-point's hypotheses are sorted along a Hilbert curve, every tile of 32 is described by a disc,
 and a pixel whose margin at the disc's centre exceeds the disc's radius (+ the rounding band) votes for all 32 hypotheses of the
 tile or for none -- only the other pixels are gathered into MFMA tiles.  The claim under test: EVERY inlier count, every winner
 and every key-point is the one the full exact kernel (and therefore literal mode, i.e. the reference's own arithmetic:
