@@ -131,9 +131,10 @@ typedef struct PvnetVoteLayout {
     int32_t reserved_;      /* 1: fast mode scores on the matrix pipe (score_mfma_kernel), 0: VALU kernel                */
     /* ABI 8 / 9 -- disc culling of the exact mode (k3_hypotheses.hip: cull_block of hypothesis_kernel; k4_score_cull.hip: score_exact_kernel_both).
      * Empty (cull = 0) unless the layout scores 8 hypothesis tiles per wave on 256-pixel work items with hn_pad = 1024 and
-     * vn <= 32.  Which key-points of a call ARE culled is decided on the device per (image, key-point) -- from the spread of
-     * the candidate intersections of the band-origin estimate (PVNET_SCORE_CULL: 2 = that, the default; 1 = all; 0 = none) --
-     * and recorded as int32 [b][vn] behind the band origins in the ctrl block.  Culled or not, every count is the same integer. */
+     * vn <= 32.  Which images of a call ARE culled is decided on the device -- an image's key-points vote from the spread of the
+     * candidate intersections of the band-origin estimate, and a batch may be culled when two thirds of the PREVIOUS batch on
+     * the same workspace voted for it (a workspace without history: yes); PVNET_F_CULL_ALL / PVNET_F_CULL_NONE override -- and
+     * recorded as int32 [b][vn] behind the band origins in the ctrl block.  Culled or not, every count is the same integer. */
     int32_t cull;           /* 1: exact-mode calls of this layout may sort a key-point's hypotheses along a Hilbert curve and
                                score only the (pixel, hypothesis tile) pairs whose outcome the tile's disc does not fix        */
     size_t off_perm;        /* int32  [b][vn][hn_pad]      sorted position -> caller's hypothesis index (>= hn: padding)        */
@@ -299,9 +300,10 @@ int pvnet_voting_for_hypothesis_vanishing_point(const float* direct, const float
 int pvnet_vote_abi_version(void);
 const char* pvnet_vote_build_info(void);
 
-/* Host-only.  The PVNET_* tuning environment variables are read ONCE, at the first call into
- * the library -- never on the launch path; this re-reads them (tests and the tuning tools change them in-process).
- * Knobs re-shape grids and work items, never results. */
+/* Host-only.  RELEASE build (libpvnet_vote.so): the tuning knobs are compile-time constants, the library reads no environment and
+ * this call does nothing.  DEVELOPMENT build (libpvnet_vote_dev.so, -DPVNET_DEV, same ABI): the PVNET_* tuning environment
+ * variables are read ONCE, at the first call into the library -- never on the launch path; this re-reads them (tests and the
+ * tuning tools change them in-process).  Knobs re-shape grids and work items, never results. */
 void pvnet_vote_tuning_reload(void);
 
 #ifdef __cplusplus

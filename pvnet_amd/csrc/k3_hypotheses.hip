@@ -19,7 +19,7 @@ __device__ __forceinline__ int plan_item_count(const VoteParams& P, int j, int* 
 }
 
 
-// culled: the disc-culling kernel scores this image's key-points (their items carry the mark)
+// culled: the disc-culling body of the scoring launch scores this image's key-points (their items carry the mark)
 __device__ __forceinline__ void plan_image(const VoteParams& P, int bi, bool culled) {
     constexpr int NT = 256;
     __shared__ int s_part[NT / 64];
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(20))) void hypo
             *kp_cull_ptr(P, (size_t)bi * P.vn + kk) = 0;
         }
     }
-    // (fill_params: P.cull implies the exact mode and vn <= KP_MAX) this image's key-points go to the disc-culling kernel
+    // (fill_params: P.cull implies the exact mode and vn <= KP_MAX) this image's key-points go to the scoring launch's disc-culling body
     // -- when the image's key-points vote for it AND the previous batch's majority did (CF_BATCH_OK, vote_common.h)
     const bool votes = !LITERAL && P.cull && kp_origin && live && image_culled(S, P.vn);
     const bool culling = votes && batch_ok;

@@ -9,16 +9,16 @@ namespace {
 // ------------------------------------------------------------------------------------------------------------
 // K4 -- disc culling (round 5; exact mode, 8 hypothesis tiles per wave, 256-pixel work items): the exact kernel's two MFMAs and
 // 40 vector operations are only spent on the (pixel, hypothesis tile) pairs whose outcome geometry does not already fix.
-// Hypotheses arrive sorted along a Hilbert curve (hypothesis_cull_kernel): a tile of 32 is a disc (centre q, radius rho_T).
+// Hypotheses arrive sorted along a Hilbert curve (cull_block of hypothesis_kernel, k3_hypotheses.hip): a tile of 32 is a disc (centre q, radius rho_T).
 //   coarse pass  per item, ONE MFMA pair per pixel tile against the 32 tile CENTRES of the item's hypothesis slice (the eight
 //                pixel tiles are shared out over the four waves): x' = s' |M_i| m_i(q).  |x'| >= 1 - g (1 - mu_i) means the
 //                pixel's margin has one sign on the whole disc, outside the rounding band for every hypothesis in it: the pixel
 //                votes for all 32 hypotheses (x' > 0: one count per tile, s_cv) or for none.  Every other pixel is UNCERTAIN
-//                for that tile and its A-row address joins the tile's list (s_list, 16-bit LDS row addresses).
+//                for that tile and its index in the item joins the tile's list (s_list, one byte per entry).
 //   fine pass    a wave walks its eight hypothesis tiles; for each it scores ceil(uncertain / 32) GATHERED pixel groups -- lane
 //                `col` of the MFMA's A operand reads the row the list names, so any 32 pixels of the item form a tile -- with
 //                the exact kernel's epilogue (vote_subs / vote_slow_open / vote_slow_close: x = dt' - |cr'|, cells of 16 tests,
-//                flagged cells re-evaluated literally).  Lists are padded to whole groups with a dead row (x = -4).
+//                flagged cells re-evaluated literally).  Lanes past a list's end read a dead row (x = -4).
 // Every count is the same integer as before: certain pixels add what the full test would have added (proof: DESIGN.md section 4),
 // uncertain ones run the very same arithmetic.  What changes is the work: on the noisy benchmark field 59 % of the steps remain
 // at thresh 0.99 (simulation: tools/cull_study.py, profiles/r05_cull_study.txt), none on a clean field.

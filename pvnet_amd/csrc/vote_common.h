@@ -465,7 +465,7 @@ constexpr int ITEM_CULL_SHIFT = 16;
 __device__ __forceinline__ int item_kp(int y) { return y & 0xFFFF; }
 __device__ __forceinline__ bool item_culled(int y) { return (y >> ITEM_CULL_SHIFT) != 0; }
 
-constexpr int CULL_NPX = 256;              // pixels per work item of the culling kernel: 8 pixel tiles, list entries are 16-bit
+constexpr int CULL_NPX = 256;              // pixels per work item of the culling body: 8 pixel tiles, list entries are one byte
 constexpr int CULL_HN = 1024;              // hypotheses per key-point (hn_pad) of the layouts that can cull: one hypothesis slice, 32 tiles,
                                            // four sort keys per thread of a 256-thread block
 constexpr int CULL_DEAD = 8 * TILE_U4_;    // uint4 index of the dead A row behind the item's 8 tiles (x = -4: no vote, no flag)
@@ -504,7 +504,7 @@ constexpr int TILE_U4 = 128;  // uint4 per 32-pixel tile: four blocks of 32 x 16
                               // the odd 16-byte slots of the 256-byte bank row: two-way conflicts on every dense read, four- to five-way on the
                               // culling kernel's gathered ones.  Now slot = row mod 16: dense reads are conflict-free, gathered ones meet
                               // sixteen slots instead of eight.)
-static_assert(TILE_U4_ == TILE_U4, "the disc-culling kernel's list addresses (CULL_DEAD, tile = a >> 7, row = a & 31) follow TILE_U4");
+static_assert(TILE_U4_ == TILE_U4, "the disc-culling body's row addresses (CULL_DEAD, tile = pixel >> 5, row = pixel & 31) follow TILE_U4");
 
 // v + (the other half-wave's v): lanes l and l ^ 32 hold different pixel rows of one hypothesis column.  gfx950's
 // v_permlane32_swap exchanges the upper row of one operand with the lower row of the other in the VALU -- no trip through
@@ -554,7 +554,7 @@ struct Tuning {
                         //                         -1 (default): runs for calls flagged PVNET_F_CONCURRENT
     int score_cull;     // PVNET_SCORE_CULL        exact mode, 8 tiles per wave, 256-pixel items, hn_pad = 1024: disc culling (hypotheses
                         //                         sorted along a Hilbert curve, per-pixel certainty against every tile's disc, uncertain
-                        //                         pixels gathered: score_exact_kernel_cull) of 2 = the key-points K3 selects from the
+                        //                         pixels gathered: the culling body of score_exact_kernel_both) of 2 = the images K3 selects from the
                         //                         spread of their candidate intersections (the default: PVNET_CULL_DEFAULT), 1 = every
                         //                         key-point (tests, probes), 0 = none (the layout then has no culling buffers)
     int cull_q_milli;   // PVNET_CULL_Q_MILLI      the selection threshold of 2, in thousandths (kp_preamble; profiles/r06y_cull_crossover.txt)
